@@ -1,0 +1,121 @@
+"""ctypes binding of libhdrmerge.so - the C ABI declared in include/hdrmerge.h.
+
+There is no CPU fallback: if the library is missing, importing this module raises, and every
+product entry point that needs it fails loudly. torch is imported first so that the HIP runtime the
+library resolves (`libamdhip64.so.7`) is the one torch already loaded - device pointers and
+streams are then shared between torch and the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+
+import torch  # noqa: F401  (must precede the CDLL: see module docstring)
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = pathlib.Path(os.environ.get("HDRMERGE_LIB", _HERE / "lib" / "libhdrmerge.so"))
+
+HM_MAX_FRAMES = 32
+HM_MAX_CHANNELS = 4
+HM_MAX_DIMS = 6
+
+HM_OK, HM_EINVAL, HM_EUNSUPPORTED, HM_EALIGN, HM_ELAUNCH, HM_ENODEVICE, HM_ESHAPE = 0, -1, -2, -3, -4, -5, -6
+HM_OP_ADD, HM_OP_SUB, HM_OP_MUL, HM_OP_DIV, HM_OP_POW = range(5)
+HM_UOP_NEG, HM_UOP_LOG_E, HM_UOP_LOG_10 = range(3)
+
+
+class HdrMergeError(RuntimeError):
+    """A libhdrmerge call returned an error that has no closer Python exception type."""
+
+
+class MergeArgs(C.Structure):
+    """struct hm_merge_args of include/hdrmerge.h (field order and types must match)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n_frames", C.c_int32), ("channels", C.c_int32), ("variant", C.c_int32),
+        ("height", C.c_int64), ("width", C.c_int64), ("row0", C.c_int64), ("rows", C.c_int64),
+        ("buf_row0", C.c_int64), ("buf_rows", C.c_int64),
+        ("frames_u8", C.POINTER(C.c_void_p)), ("frames_f64", C.POINTER(C.c_void_p)),
+        ("stds", C.POINTER(C.c_void_p)), ("exposures", C.POINTER(C.c_double)),
+        ("icrf", C.c_void_p), ("icrf_diff", C.c_void_p), ("w_lut", C.c_void_p), ("dw_lut", C.c_void_p),
+        ("darks_u8", C.POINTER(C.c_void_p)), ("dark_min_dn", C.POINTER(C.c_int32)),
+        ("median_k", C.c_int32), ("_pad0", C.c_int32),
+        ("flat_u8", C.c_void_p), ("flat_f64", C.c_void_p), ("flat_std", C.c_void_p),
+        ("ff_mean", C.c_double * HM_MAX_CHANNELS), ("ff_std_mean", C.c_double * HM_MAX_CHANNELS),
+        ("out_val", C.c_void_p), ("out_std", C.c_void_p), ("out_sum_w", C.c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "hm_version": (C.c_int, []),
+    "hm_strerror": (C.c_char_p, [C.c_int]),
+    "hm_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "hm_gaussian_weight_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_gaussian_weight_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_gaussian_weight_lut_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "hm_u8_to_unit_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_linearize_u8": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "hm_linearize_f64": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "hm_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
+    "hm_merge_algorithmic_bytes": (C.c_int64, [C.POINTER(MergeArgs)]),
+    "hm_hot_pixel_filter_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                         C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "hm_hot_pixel_filter_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                          C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "hm_roi_mean_workspace_bytes": (C.c_size_t, []),
+    "hm_roi_mean_u8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hm_roi_mean_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hm_normalize_by_map": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "hm_binary_op": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                              C.POINTER(C.c_int64), C.c_void_p]),
+    "hm_unary_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"libhdrmerge.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C camera_linearity_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared entry point
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+if lib.hm_version() != 1:
+    raise ImportError(f"libhdrmerge ABI version {lib.hm_version()} != 1 expected by this package")
+
+
+def strerror(code: int) -> str:
+    return lib.hm_strerror(code).decode()
+
+
+def check(code: int, what: str = "libhdrmerge") -> None:
+    """Map hm_* status codes to the exception types the reference raises for the same misuse
+    (ValueError for shape/argument problems, modules/measurand.py:112,404,710)."""
+    if code == HM_OK:
+        return
+    msg = f"{what}: {strerror(code)} ({code})"
+    if code in (HM_EINVAL, HM_ESHAPE, HM_EALIGN):
+        raise ValueError(msg)
+    if code == HM_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HdrMergeError(msg)
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None stays NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

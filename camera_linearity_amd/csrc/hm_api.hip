@@ -1,0 +1,44 @@
+// hm_api.hip - version / error strings / device query / host-side weight table of libhdrmerge.
+#include "hm_common.h"
+#include <cmath>
+#include <cstring>
+
+extern "C" int hm_version(void) { return HM_ABI_VERSION; }
+
+extern "C" const char* hm_strerror(int code) {
+    switch (code) {
+        case HM_OK: return "ok";
+        case HM_EINVAL: return "invalid argument";
+        case HM_EUNSUPPORTED: return "unsupported configuration (frames > HM_MAX_FRAMES or channels > HM_MAX_CHANNELS)";
+        case HM_EALIGN: return "float64 buffer is not 8-byte aligned";
+        case HM_ELAUNCH: return "HIP kernel launch failed";
+        case HM_ENODEVICE: return "no usable gfx950 device";
+        case HM_ESHAPE: return "inconsistent geometry (tile outside image or median halo missing)";
+        default: return "unknown hdrmerge error";
+    }
+}
+
+extern "C" int hm_device_info(int* n_devices, int* cu_count, int* lds_bytes, char* arch, int arch_len) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); if (n_devices) *n_devices = 0; return HM_ENODEVICE; }
+    if (n_devices) *n_devices = n;
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return HM_ENODEVICE; }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = static_cast<int>(p.maxSharedMemoryPerMultiProcessor);
+    if (arch && arch_len > 0) { std::strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    return HM_OK;
+}
+
+// modules/measurand.py:615-616 on the DN grid v = k/255, evaluated with libm
+extern "C" int hm_gaussian_weight_lut_host(double* w_lut, double* dw_lut) {
+    if (!w_lut && !dw_lut) return HM_EINVAL;
+    for (int k = 0; k < HM_BITS; ++k) {
+        const double v = static_cast<double>(k) / 255.0;
+        const double y = std::pow(M_E, -30.0 * ((v - 0.5) * (v - 0.5)));
+        if (w_lut) w_lut[k] = y;
+        if (dw_lut) dw_lut[k] = ((-2.0 * 30.0) * (v - 0.5)) * y;
+    }
+    return HM_OK;
+}

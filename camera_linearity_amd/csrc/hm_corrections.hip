@@ -1,0 +1,205 @@
+// hm_corrections.hip - dark-frame hot-pixel filter and flat-field correction as standalone launches.
+//   hm_hot_pixel_filter_*   AbstractMeasurand.filter_larger_than_by_map, modules/measurand.py:543-557
+//                           (intended semantics, SURVEY.md 3.4-F: masked pixels <- k x k median, 'reflect')
+//   hm_roi_mean_*           flat_field_mean, modules/measurand.py:561-579 (integer ROI)
+//   hm_normalize_by_map     modules/measurand.py:585-604
+#include "hm_common.h"
+#include <algorithm>
+
+namespace hm {
+
+// median by counting, same selection rule as the fused kernel (hm_merge.hip)
+template <typename T>
+__device__ T median_full(const T* __restrict__ buf, int64_t H, int64_t W, int C, int64_t row, int64_t col, int c, int k) {
+    const int r = k / 2, m = (k * k) / 2;
+    T best = buf[(row * W + col) * C + c];
+    for (int py = -r; py <= r; ++py) {
+        const int64_t yy = reflect_index(row + py, H);
+        for (int px = -r; px <= r; ++px) {
+            const T v = buf[(yy * W + reflect_index(col + px, W)) * C + c];
+            int less = 0, leq = 0;
+            for (int qy = -r; qy <= r; ++qy) {
+                const int64_t y2 = reflect_index(row + qy, H);
+                for (int qx = -r; qx <= r; ++qx) {
+                    const T u = buf[(y2 * W + reflect_index(col + qx, W)) * C + c];
+                    less += (u < v);
+                    leq += (u <= v);
+                }
+            }
+            if (less <= m && m < leq) best = v;
+        }
+    }
+    return best;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_hot_filter(const T* __restrict__ x, const uint8_t* __restrict__ map_u8,
+                                                    const double* __restrict__ map_f64, int min_dn, double thr, int k,
+                                                    T* __restrict__ out, int64_t H, int64_t W, int C) {
+    const int64_t n = H * W * C;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const bool hot = map_u8 ? (static_cast<int>(map_u8[e]) >= min_dn) : (map_f64[e] > thr);   // measurand.py:545
+        T v = x[e];
+        if (hot) {
+            const int64_t wc = W * C;
+            const int64_t row = e / wc, rem = e % wc;
+            v = median_full(x, H, W, C, row, rem / C, static_cast<int>(rem % C), k);
+        }
+        out[e] = v;
+    }
+}
+
+// ---- ROI mean: stage 1 = per-block partial sums per channel (wave shuffles + LDS), stage 2 = one block ----
+constexpr int kRoiBlocks = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_roi_partial(const T* __restrict__ img, int64_t W, int C,
+                                                     int64_t x0, int64_t x1, int64_t y0, int64_t y1,
+                                                     double* __restrict__ partial /*[gridDim.x][HM_MAX_CHANNELS]*/) {
+    __shared__ double red[4][HM_MAX_CHANNELS];
+    const int64_t roi_w = (y1 - y0) * C;                 // contiguous elements per ROI row
+    const int64_t total = (x1 - x0) * roi_w;
+    double acc[HM_MAX_CHANNELS] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const int64_t r = q / roi_w, o = q % roi_w;
+        const double v = static_cast<double>(img[(x0 + r) * W * C + y0 * C + o]);
+        const int c = static_cast<int>(o % C);
+#pragma unroll
+        for (int k = 0; k < HM_MAX_CHANNELS; ++k) acc[k] += (k == c) ? v : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < HM_MAX_CHANNELS; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < HM_MAX_CHANNELS)
+        partial[blockIdx.x * HM_MAX_CHANNELS + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_roi_final(const double* __restrict__ partial, int nblocks, int C,
+                                                   double count, double div, double* __restrict__ out) {
+    __shared__ double red[4][HM_MAX_CHANNELS];
+    double acc[HM_MAX_CHANNELS] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < HM_MAX_CHANNELS; ++k) acc[k] += partial[b * HM_MAX_CHANNELS + k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < HM_MAX_CHANNELS; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < C)
+        out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / div) / count;
+}
+
+// ---- normalize_by_map ----
+struct FFMeans { double m[HM_MAX_CHANNELS]; double s[HM_MAX_CHANNELS]; };
+
+__global__ __launch_bounds__(256) void k_normalize(const double* __restrict__ val, const double* __restrict__ sd,
+                                                   const uint8_t* __restrict__ flat_u8, const double* __restrict__ flat_f64,
+                                                   const double* __restrict__ flat_std, const FFMeans ff,
+                                                   double* __restrict__ out_val, double* __restrict__ out_std,
+                                                   int64_t n, int C) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        const double F = flat_u8 ? static_cast<double>(flat_u8[e]) / 255.0 : flat_f64[e];
+        const double m = ff.m[c];
+        const double v = val[e];
+        if (out_std) {
+            const double s0 = sd[e], sF = flat_std[e], s = ff.s[c];
+            const double F2 = F * F;
+            double u_acq = (s0 * s0) / F2;        // measurand.py:586-587
+            u_acq *= m * m;
+            double u_ff = (v * v) / (F2 * F2);    // :590-592
+            u_ff *= sF * sF;
+            u_ff *= m * m;
+            double u_ffm = (v * v) / F2;          // :595-596
+            u_ffm *= s * s;
+            out_std[e] = sqrt(u_acq + u_ff + u_ffm);   // :599
+        }
+        out_val[e] = (v / F) * m;                 // :602
+    }
+}
+
+template <typename T>
+static int hot_filter_common(const T* x, const uint8_t* map_u8, const double* map_f64, int min_dn, double thr, int k,
+                             T* out, int64_t H, int64_t W, int C, void* stream) {
+    if (H < 0 || W < 0 || C < 1) return HM_EINVAL;
+    const int64_t n = H * W * C;
+    if (n == 0) return HM_OK;
+    if (!x || !out || (!map_u8 && !map_f64) || x == out) return HM_EINVAL;
+    if (k < 3 || k > 7 || (k % 2) == 0) return HM_EINVAL;
+    if (sizeof(T) == 8 && (!aligned(x, 8) || !aligned(out, 8))) return HM_EALIGN;
+    hipLaunchKernelGGL(k_hot_filter<T>, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
+                       x, map_u8, map_f64, min_dn, thr, k, out, H, W, C);
+    return launch_status();
+}
+
+template <typename T>
+static int roi_mean_common(const T* img, int64_t H, int64_t W, int C, int64_t x0, int64_t x1, int64_t y0, int64_t y1,
+                           double div, double* out_mean, void* workspace, void* stream) {
+    if (!img || !out_mean || !workspace || C < 1 || C > HM_MAX_CHANNELS) return HM_EINVAL;
+    if (x0 < 0 || y0 < 0 || x1 > H || y1 > W || x1 <= x0 || y1 <= y0) return HM_ESHAPE;
+    const int64_t total = (x1 - x0) * (y1 - y0) * C;
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(kRoiBlocks, (total + 255) / 256));
+    double* partial = static_cast<double*>(workspace);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_roi_partial<T>, dim3(grid), dim3(256), 0, st, img, W, C, x0, x1, y0, y1, partial);
+    hipLaunchKernelGGL(k_roi_final, dim3(1), dim3(256), 0, st, partial, static_cast<int>(grid), C,
+                       static_cast<double>((x1 - x0) * (y1 - y0)), div, out_mean);
+    return launch_status();
+}
+
+}  // namespace hm
+
+using namespace hm;
+
+extern "C" int hm_hot_pixel_filter_u8(const uint8_t* x, const uint8_t* map_u8, const double* map_f64, int min_dn,
+                                      double thr, int median_k, uint8_t* out, int64_t H, int64_t W, int C, void* stream) {
+    return hot_filter_common<uint8_t>(x, map_u8, map_f64, min_dn, thr, median_k, out, H, W, C, stream);
+}
+extern "C" int hm_hot_pixel_filter_f64(const double* x, const uint8_t* map_u8, const double* map_f64, int min_dn,
+                                       double thr, int median_k, double* out, int64_t H, int64_t W, int C, void* stream) {
+    return hot_filter_common<double>(x, map_u8, map_f64, min_dn, thr, median_k, out, H, W, C, stream);
+}
+
+extern "C" size_t hm_roi_mean_workspace_bytes(void) { return sizeof(double) * kRoiBlocks * HM_MAX_CHANNELS; }
+
+extern "C" int hm_roi_mean_u8(const uint8_t* img, int64_t H, int64_t W, int C, int64_t x0, int64_t x1, int64_t y0,
+                              int64_t y1, double* out_mean, void* workspace, void* stream) {
+    // mean of DN/255 values: sum the integer DNs exactly, scale once
+    return roi_mean_common<uint8_t>(img, H, W, C, x0, x1, y0, y1, 255.0, out_mean, workspace, stream);
+}
+extern "C" int hm_roi_mean_f64(const double* img, int64_t H, int64_t W, int C, int64_t x0, int64_t x1, int64_t y0,
+                               int64_t y1, double* out_mean, void* workspace, void* stream) {
+    if (img && !aligned(img, 8)) return HM_EALIGN;
+    return roi_mean_common<double>(img, H, W, C, x0, x1, y0, y1, 1.0, out_mean, workspace, stream);
+}
+
+extern "C" int hm_normalize_by_map(const double* val, const double* std, const uint8_t* flat_u8, const double* flat_f64,
+                                   const double* flat_std, const double* ff_mean, const double* ff_std_mean,
+                                   double* out_val, double* out_std, int64_t n, int C, void* stream) {
+    if (n < 0 || C < 1 || C > HM_MAX_CHANNELS) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!val || !out_val || !ff_mean || (!flat_u8 == !flat_f64)) return HM_EINVAL;
+    if (out_std && (!std || !flat_std || !ff_std_mean)) return HM_EINVAL;
+    FFMeans ff{};
+    for (int c = 0; c < C; ++c) { ff.m[c] = ff_mean[c]; ff.s[c] = ff_std_mean ? ff_std_mean[c] : 0.0; }
+    hipLaunchKernelGGL(k_normalize, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
+                       val, std, flat_u8, flat_f64, flat_std, ff, out_val, out_std, n, C);
+    return launch_status();
+}

@@ -1,0 +1,183 @@
+// hm_linearize.hip - the per-frame pieces of the hot path as standalone launches (gfx950):
+//   hm_u8_to_unit_f64       modules/image_set.py:223        value = DN / 255
+//   hm_gaussian_weight_*    modules/measurand.py:606-618    w, dw
+//   hm_linearize_*          modules/measurand.py:471-541    ICRF LUT gather (+ ICRF_diff * std)
+// All are streaming kernels: 16-byte loads/stores per lane, LUTs staged in LDS, grid-stride over
+// "units" of 4 (uint8 input) or 2 (float64 input) consecutive elements.
+#include "hm_common.h"
+
+namespace hm {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void st2(double* p, double x, double y) {
+    f64x2 v; v.x = x; v.y = y;
+    *reinterpret_cast<f64x2*>(p) = v;
+}
+
+// ---------------- u8 -> DN/255 ----------------
+__global__ __launch_bounds__(256) void k_u8_to_unit(const uint8_t* __restrict__ dn, double* __restrict__ out, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t units = n / 4;
+    const bool vec_ok = aligned_dev(dn, 4) && aligned_dev(out, 16);
+    for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < units; u += stride) {
+        uint32_t r;
+        if (vec_ok) r = *reinterpret_cast<const uint32_t*>(dn + 4 * u);
+        else r = dn[4 * u] | (dn[4 * u + 1] << 8) | (dn[4 * u + 2] << 16) | (static_cast<uint32_t>(dn[4 * u + 3]) << 24);
+        const double a = static_cast<double>(r & 255u) / 255.0, b = static_cast<double>((r >> 8) & 255u) / 255.0;
+        const double c = static_cast<double>((r >> 16) & 255u) / 255.0, d = static_cast<double>(r >> 24) / 255.0;
+        if (vec_ok) { st2(out + 4 * u, a, b); st2(out + 4 * u + 2, c, d); }
+        else { out[4 * u] = a; out[4 * u + 1] = b; out[4 * u + 2] = c; out[4 * u + 3] = d; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t e = units * 4 + threadIdx.x;
+        out[e] = static_cast<double>(dn[e]) / 255.0;
+    }
+}
+
+// ---------------- gaussian weight ----------------
+__global__ __launch_bounds__(256) void k_weight_f64(const double* __restrict__ v, double* __restrict__ w,
+                                                    double* __restrict__ dw, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const double d = v[e] - 0.5;
+        const double y = exp(-30.0 * (d * d));          // np.e ** (-30 (v - 0.5)^2), measurand.py:615
+        if (w) w[e] = y;
+        if (dw) dw[e] = (-60.0 * d) * y;                // -2 * 30 * (v - 0.5) * y, measurand.py:616
+    }
+}
+
+__global__ __launch_bounds__(256) void k_weight_u8(const uint8_t* __restrict__ dn, const double* __restrict__ w_lut,
+                                                   const double* __restrict__ dw_lut, double* __restrict__ w,
+                                                   double* __restrict__ dw, int64_t n) {
+    __shared__ double t_w[256], t_dw[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { t_w[i] = w_lut[i]; t_dw[i] = dw_lut ? dw_lut[i] : 0.0; }
+    __syncthreads();
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const uint32_t k = dn[e];
+        if (w) w[e] = t_w[k];
+        if (dw) dw[e] = t_dw[k];
+    }
+}
+
+// ---------------- linearize ----------------
+// LUT in LDS as {g, d} 16-byte entries, index idx * lut_stride + (e % C) * (lut_stride > 1)
+template <bool F64IN>
+__global__ __launch_bounds__(256) void k_linearize(const void* __restrict__ in, const double* __restrict__ sd,
+                                                   const double* __restrict__ icrf, const double* __restrict__ icrf_diff,
+                                                   double* __restrict__ out_val, double* __restrict__ out_std,
+                                                   uint8_t* __restrict__ out_idx, int64_t n, int C, int lut_stride) {
+    __shared__ double2 t[256 * HM_MAX_CHANNELS];
+    const int entries = 256 * lut_stride;
+    const bool with_std = sd && icrf_diff && out_std;           // measurand.py:498-500
+    for (int i = threadIdx.x; i < entries; i += blockDim.x) t[i] = double2{icrf[i], with_std ? icrf_diff[i] : 0.0};
+    __syncthreads();
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const bool per_ch = lut_stride > 1;
+    if (!F64IN) {
+        const uint8_t* dn = static_cast<const uint8_t*>(in);
+        const int64_t units = n / 4;
+        const bool vec_ok = aligned_dev(dn, 4) && aligned_dev(out_val, 16) && (!with_std || (aligned_dev(sd, 16) && aligned_dev(out_std, 16)));
+        for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < units; u += stride) {
+            const int64_t e0 = 4 * u;
+            uint32_t r;
+            if (vec_ok) r = *reinterpret_cast<const uint32_t*>(dn + e0);
+            else r = dn[e0] | (dn[e0 + 1] << 8) | (dn[e0 + 2] << 16) | (static_cast<uint32_t>(dn[e0 + 3]) << 24);
+            int c = per_ch ? static_cast<int>(e0 % C) : 0;
+            double g[4], ds[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t k = (r >> (8 * j)) & 255u;
+                const double2 gd = t[k * lut_stride + c];
+                g[j] = gd.x; ds[j] = gd.y;
+                if (per_ch) { ++c; if (c == C) c = 0; }
+            }
+            if (with_std) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ds[j] = ds[j] * sd[e0 + j];                  // measurand.py:512
+            }
+            if (vec_ok) {
+                st2(out_val + e0, g[0], g[1]); st2(out_val + e0 + 2, g[2], g[3]);
+                if (with_std) { st2(out_std + e0, ds[0], ds[1]); st2(out_std + e0 + 2, ds[2], ds[3]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { out_val[e0 + j] = g[j]; if (with_std) out_std[e0 + j] = ds[j]; }
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const int64_t e = units * 4 + threadIdx.x;
+            const double2 gd = t[dn[e] * lut_stride + (per_ch ? static_cast<int>(e % C) : 0)];
+            out_val[e] = gd.x;
+            if (with_std) out_std[e] = gd.y * sd[e];
+        }
+    } else {
+        const double* v = static_cast<const double*>(in);
+        for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+            // around(val * MAX_DN).astype(uint8): round half to even, then wrap (measurand.py:503)
+            const uint32_t k = static_cast<uint32_t>(static_cast<int64_t>(rint(v[e] * 255.0))) & 255u;
+            const double2 gd = t[k * lut_stride + (per_ch ? static_cast<int>(e % C) : 0)];
+            out_val[e] = gd.x;
+            if (with_std) out_std[e] = gd.y * sd[e];
+            if (out_idx) out_idx[e] = static_cast<uint8_t>(k);
+        }
+    }
+}
+
+}  // namespace hm
+
+using namespace hm;
+
+extern "C" int hm_u8_to_unit_f64(const uint8_t* dn, double* out, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!dn || !out))) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!aligned(out, 8)) return HM_EALIGN;
+    hipLaunchKernelGGL(k_u8_to_unit, dim3(stream_grid((n + 3) / 4, 256, 8)), dim3(256), 0, as_stream(stream), dn, out, n);
+    return launch_status();
+}
+
+extern "C" int hm_gaussian_weight_f64(const double* v, double* w, double* dw, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!v || (!w && !dw)))) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!aligned(v, 8) || (w && !aligned(w, 8)) || (dw && !aligned(dw, 8))) return HM_EALIGN;
+    hipLaunchKernelGGL(k_weight_f64, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), v, w, dw, n);
+    return launch_status();
+}
+
+extern "C" int hm_gaussian_weight_u8(const uint8_t* dn, const double* w_lut, const double* dw_lut,
+                                     double* w, double* dw, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!dn || !w_lut || (!w && !dw) || (dw && !dw_lut)))) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if ((w && !aligned(w, 8)) || (dw && !aligned(dw, 8))) return HM_EALIGN;
+    hipLaunchKernelGGL(k_weight_u8, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), dn, w_lut, dw_lut, w, dw, n);
+    return launch_status();
+}
+
+static int linearize_common(bool f64in, const void* in, const double* sd, const double* icrf, const double* icrf_diff,
+                            double* out_val, double* out_std, uint8_t* out_idx, int64_t n, int C, int lut_stride, void* stream) {
+    if (n < 0 || C < 1 || !icrf || (n > 0 && (!in || !out_val))) return HM_EINVAL;
+    if (lut_stride != 1 && lut_stride != C) return HM_EINVAL;
+    if (C > HM_MAX_CHANNELS && lut_stride != 1) return HM_EUNSUPPORTED;
+    if (n == 0) return HM_OK;
+    if (!aligned(out_val, 8) || (out_std && !aligned(out_std, 8)) || (sd && !aligned(sd, 8)) || (f64in && !aligned(in, 8)))
+        return HM_EALIGN;
+    const unsigned grid = stream_grid(f64in ? n : (n + 3) / 4, 256, 8);
+    if (f64in)
+        hipLaunchKernelGGL(k_linearize<true>, dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff,
+                           out_val, out_std, out_idx, n, C, lut_stride);
+    else
+        hipLaunchKernelGGL(k_linearize<false>, dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff,
+                           out_val, out_std, out_idx, n, C, lut_stride);
+    return launch_status();
+}
+
+extern "C" int hm_linearize_u8(const uint8_t* dn, const double* std, const double* icrf, const double* icrf_diff,
+                               double* out_val, double* out_std, int64_t n, int C, int lut_stride, void* stream) {
+    return linearize_common(false, dn, std, icrf, icrf_diff, out_val, out_std, nullptr, n, C, lut_stride, stream);
+}
+
+extern "C" int hm_linearize_f64(const double* v, const double* std, const double* icrf, const double* icrf_diff,
+                                double* out_val, double* out_std, uint8_t* out_idx,
+                                int64_t n, int C, int lut_stride, void* stream) {
+    return linearize_common(true, v, std, icrf, icrf_diff, out_val, out_std, out_idx, n, C, lut_stride, stream);
+}

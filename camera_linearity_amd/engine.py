@@ -1,0 +1,474 @@
+"""Functional layer over the C ABI: torch device tensors in, torch device tensors out.
+
+Everything here is plumbing - argument checking, pointer tables, output allocation - around the
+hand-written HIP kernels in csrc/. No arithmetic of the hot path happens in Python or in torch ops.
+The only host-side numbers are the 256-entry Gaussian weight tables (modules/measurand.py:615-616
+evaluated on the DN grid with NumPy, so that they are bit-identical to what the reference computes
+for 8-bit frames) and per-frame scalars (1/exposure, DN thresholds).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .settings import BITS, MAX_DN
+
+_F64 = torch.float64
+_U8 = torch.uint8
+
+
+# ---------------------------------------------------------------------------------------------
+# small helpers
+# ---------------------------------------------------------------------------------------------
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)} instead.")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} lives on {t.device}; the HIP backend only computes on device tensors "
+                           "(there is no CPU fallback)")
+
+
+def _dev_f64(x, device) -> torch.Tensor:
+    """float64 contiguous tensor on `device` from a tensor / ndarray / sequence (tables, not images)."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=_F64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float64)), device=device)
+
+
+def _ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+_weight_cache: Dict[str, tuple] = {}
+
+
+def weight_luts_host():
+    """w, dw on the DN grid v = k/255: modules/measurand.py:615-616 with NumPy (`np.e ** x`)."""
+    v = np.arange(BITS, dtype=np.uint8).astype(np.float64) / MAX_DN       # modules/image_set.py:223
+    w = np.e ** (-30 * (v - 0.5) ** 2)
+    dw = -2 * 30 * (v - 0.5) * w
+    return w, dw
+
+
+def weight_luts(device) -> tuple:
+    key = str(torch.device(device))
+    if key not in _weight_cache:
+        w, dw = weight_luts_host()
+        _weight_cache[key] = (torch.as_tensor(w, device=device), torch.as_tensor(dw, device=device))
+    return _weight_cache[key]
+
+
+def dark_min_dn(scale: float, threshold: float) -> int:
+    """Smallest dark DN that counts as hot: the reference tests `dark.val > threshold`
+    (modules/measurand.py:545) with dark.val = (DN/255) * scale (modules/image_set.py:223,260);
+    evaluated here for all 256 DNs with the same float64 operations, so the DN-domain comparison the
+    kernel performs (`dark_dn >= min_dn`) is exactly equivalent. Returns 256 when no DN is hot."""
+    v = np.arange(BITS, dtype=np.uint8).astype(np.float64) / MAX_DN
+    if scale != 1.0:
+        v = np.array([scale], dtype=np.float64) * v                       # Measurand(scale) * dark, measurand.py:198
+    hot = np.nonzero(v > threshold)[0]
+    return int(hot[0]) if hot.size else BITS
+
+
+def _stream(device) -> int:
+    return nat.current_stream_ptr(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# rows 1, 3, 4: per-frame kernels
+# ---------------------------------------------------------------------------------------------
+def u8_to_unit(dn: torch.Tensor) -> torch.Tensor:
+    """modules/image_set.py:223."""
+    _require_cuda(dn, "dn")
+    dn = dn.contiguous()
+    out = torch.empty(dn.shape, dtype=_F64, device=dn.device)
+    with torch.cuda.device(dn.device):
+        nat.check(nat.lib.hm_u8_to_unit_f64(dn.data_ptr(), out.data_ptr(), dn.numel(), _stream(dn.device)), "hm_u8_to_unit_f64")
+    return out
+
+
+def gaussian_weight(val: torch.Tensor):
+    """modules/measurand.py:606-618 -> (w, dw)."""
+    _require_cuda(val, "val")
+    val = val.contiguous()
+    w = torch.empty(val.shape, dtype=_F64, device=val.device)
+    dw = torch.empty(val.shape, dtype=_F64, device=val.device)
+    with torch.cuda.device(val.device):
+        if val.dtype == _U8:
+            wl, dwl = weight_luts(val.device)
+            rc = nat.lib.hm_gaussian_weight_u8(val.data_ptr(), wl.data_ptr(), dwl.data_ptr(), w.data_ptr(), dw.data_ptr(),
+                                               val.numel(), _stream(val.device))
+        elif val.dtype == _F64:
+            rc = nat.lib.hm_gaussian_weight_f64(val.data_ptr(), w.data_ptr(), dw.data_ptr(), val.numel(), _stream(val.device))
+        else:
+            raise TypeError(f"gaussian_weight expects uint8 or float64, got {val.dtype}")
+    nat.check(rc, "hm_gaussian_weight")
+    return w, dw
+
+
+def linearize(val: torch.Tensor, std: Optional[torch.Tensor], icrf, icrf_diff=None, return_index: bool = False):
+    """modules/measurand.py:471-541. `icrf` is (256, C) or 1-D (256,). Returns (val, std|None[, idx])."""
+    _require_cuda(val, "val")
+    dev = val.device
+    val = val.contiguous()
+    icrf_t = _dev_f64(icrf, dev)
+    diff_t = None if icrf_diff is None else _dev_f64(icrf_diff, dev)
+    C_ = val.shape[-1] if val.dim() > 0 else 1
+    if icrf_t.dim() == 1:
+        lut_stride = 1
+    else:
+        if icrf_t.shape[-1] != C_:
+            raise ValueError(f"ICRF has {icrf_t.shape[-1]} channels, value has {C_}")
+        lut_stride = C_
+    if icrf_t.shape[0] != BITS:
+        raise ValueError(f"ICRF must have {BITS} rows, got {icrf_t.shape[0]}")
+    use_std = std is not None and diff_t is not None                      # measurand.py:498-500
+    if use_std:
+        _require_cuda(std, "std")
+        if std.shape != val.shape:
+            raise ValueError("Value and std shapes must match.")
+        std = std.to(_F64).contiguous()
+    out_val = torch.empty(val.shape, dtype=_F64, device=dev)
+    out_std = torch.empty(val.shape, dtype=_F64, device=dev) if use_std else None
+    idx = None
+    with torch.cuda.device(dev):
+        if val.dtype == _U8:
+            rc = nat.lib.hm_linearize_u8(val.data_ptr(), nat.ptr(std) if use_std else None, icrf_t.data_ptr(), nat.ptr(diff_t),
+                                         out_val.data_ptr(), nat.ptr(out_std), val.numel(), C_, lut_stride, _stream(dev))
+            if return_index:
+                idx = val.clone()                                          # measurand.py:505
+        elif val.dtype == _F64:
+            if return_index:
+                idx = torch.empty(val.shape, dtype=_U8, device=dev)
+            rc = nat.lib.hm_linearize_f64(val.data_ptr(), nat.ptr(std) if use_std else None, icrf_t.data_ptr(), nat.ptr(diff_t),
+                                          out_val.data_ptr(), nat.ptr(out_std), nat.ptr(idx), val.numel(), C_, lut_stride,
+                                          _stream(dev))
+        else:
+            raise TypeError(f"linearize expects uint8 or float64 values, got {val.dtype}")
+    nat.check(rc, "hm_linearize")
+    return (out_val, out_std, idx) if return_index else (out_val, out_std)
+
+
+# ---------------------------------------------------------------------------------------------
+# rows 8, 9 standalone
+# ---------------------------------------------------------------------------------------------
+def hot_pixel_filter(x: torch.Tensor, dark_map: torch.Tensor, threshold: float, median_k: int,
+                     min_dn: Optional[int] = None) -> torch.Tensor:
+    """modules/measurand.py:543-557 (intended semantics). `dark_map` is a uint8 DN map (hot iff
+    DN >= min_dn; min_dn defaults to dark_min_dn(1.0, threshold)) or a float64 value map (hot iff > threshold)."""
+    _require_cuda(x, "x")
+    _require_cuda(dark_map, "dark_map")
+    if x.dim() != 3 or dark_map.shape != x.shape:
+        raise ValueError("hot_pixel_filter expects (H, W, C) arrays of equal shape")
+    x = x.contiguous()
+    dark_map = dark_map.contiguous()
+    H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    mu8 = dark_map.data_ptr() if dark_map.dtype == _U8 else None
+    mf64 = dark_map.data_ptr() if dark_map.dtype == _F64 else None
+    if mu8 is None and mf64 is None:
+        raise TypeError("dark map must be uint8 or float64")
+    if min_dn is None:
+        min_dn = dark_min_dn(1.0, threshold)
+    fn = {_U8: nat.lib.hm_hot_pixel_filter_u8, _F64: nat.lib.hm_hot_pixel_filter_f64}.get(x.dtype)
+    if fn is None:
+        raise TypeError("hot_pixel_filter expects uint8 or float64 data")
+    with torch.cuda.device(x.device):
+        nat.check(fn(x.data_ptr(), mu8, mf64, int(min_dn), float(threshold), int(median_k), out.data_ptr(), H, W, Cc,
+                     _stream(x.device)), "hm_hot_pixel_filter")
+    return out
+
+
+def flat_roi_bounds(size_x: int, size_y: int, p: float):
+    """modules/measurand.py:570-576 with the integer ROI index."""
+    import math
+    dx = math.floor(size_x * p)
+    dy = math.floor(size_y * p)
+    i = (math.floor(1 / p) - 1) // 2
+    return i * dx, (i + 1) * dx, i * dy, (i + 1) * dy
+
+
+def roi_mean(img: torch.Tensor, x0: int, x1: int, y0: int, y1: int) -> torch.Tensor:
+    """modules/measurand.py:579 - per-channel mean over img[x0:x1, y0:y1, :] (uint8 images are DN/255)."""
+    _require_cuda(img, "img")
+    if img.dim() != 3:
+        raise ValueError("roi_mean expects an (H, W, C) image")
+    img = img.contiguous()
+    H, W, Cc = img.shape
+    out = torch.empty(Cc, dtype=_F64, device=img.device)
+    ws = torch.empty(nat.lib.hm_roi_mean_workspace_bytes() // 8, dtype=_F64, device=img.device)
+    fn = {_U8: nat.lib.hm_roi_mean_u8, _F64: nat.lib.hm_roi_mean_f64}.get(img.dtype)
+    if fn is None:
+        raise TypeError("roi_mean expects uint8 or float64")
+    with torch.cuda.device(img.device):
+        nat.check(fn(img.data_ptr(), H, W, Cc, x0, x1, y0, y1, out.data_ptr(), ws.data_ptr(), _stream(img.device)), "hm_roi_mean")
+    return out
+
+
+def normalize_by_map(val: torch.Tensor, std: Optional[torch.Tensor], flat: torch.Tensor, flat_std: Optional[torch.Tensor],
+                     ff_mean, ff_std_mean=None):
+    """modules/measurand.py:585-604. `flat` uint8 DN or float64; means are host sequences of C floats."""
+    _require_cuda(val, "val")
+    val = val.contiguous()
+    flat = flat.contiguous()
+    Cc = val.shape[-1]
+    m = (C.c_double * nat.HM_MAX_CHANNELS)(*[float(x) for x in ff_mean])
+    s = (C.c_double * nat.HM_MAX_CHANNELS)(*[float(x) for x in (ff_std_mean if ff_std_mean is not None else [0.0] * Cc)])
+    out_val = torch.empty_like(val)
+    out_std = torch.empty_like(val) if std is not None else None
+    with torch.cuda.device(val.device):
+        nat.check(nat.lib.hm_normalize_by_map(
+            val.data_ptr(), nat.ptr(std.contiguous()) if std is not None else None,
+            flat.data_ptr() if flat.dtype == _U8 else None, flat.data_ptr() if flat.dtype == _F64 else None,
+            nat.ptr(flat_std.contiguous()) if flat_std is not None else None,
+            C.cast(m, C.POINTER(C.c_double)), C.cast(s, C.POINTER(C.c_double)),
+            out_val.data_ptr(), nat.ptr(out_std), val.numel(), Cc, _stream(val.device)), "hm_normalize_by_map")
+    return out_val, out_std
+
+
+# ---------------------------------------------------------------------------------------------
+# rows 5-9 fused: the merge
+# ---------------------------------------------------------------------------------------------
+class MergePlan:
+    """A validated hm_merge_args plus the tensors it points into (kept alive until the plan dies).
+    `launch()` enqueues the fused kernel on the current stream of the plan's device; it can be called
+    repeatedly (bench, hipGraph capture)."""
+
+    def __init__(self, args: nat.MergeArgs, keep: list, device, outputs: dict):
+        self.args = args
+        self._keep = keep
+        self.device = device
+        self.outputs = outputs
+
+    def launch(self, stream: Optional[int] = None) -> None:
+        with torch.cuda.device(self.device):
+            rc = nat.lib.hm_merge(C.byref(self.args), _stream(self.device) if stream is None else stream)
+        nat.check(rc, "hm_merge")
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(nat.lib.hm_merge_algorithmic_bytes(C.byref(self.args)))
+
+
+def plan_merge(frames: Sequence[torch.Tensor], exposures: Sequence[float], icrf, icrf_diff=None,
+               stds: Optional[Sequence[torch.Tensor]] = None,
+               darks: Optional[Sequence[Optional[torch.Tensor]]] = None,
+               dark_min: Optional[Sequence[int]] = None, median_k: int = 3,
+               flat: Optional[torch.Tensor] = None, flat_std: Optional[torch.Tensor] = None,
+               ff_mean=None, ff_std_mean=None, want_sum_w: bool = False, want_val: bool = True,
+               height: Optional[int] = None, row0: int = 0, rows: Optional[int] = None, buf_row0: int = 0,
+               variant: int = 0) -> MergePlan:
+    """Build the launch descriptor for one fused merge (modules/exposure_series.py:317-419).
+
+    frames : N tensors (buf_rows, W, C), all uint8 DNs or all float64 values, ascending exposure.
+             They cover image rows [buf_row0, buf_row0 + buf_rows) of an image `height` rows tall;
+             the call produces rows [row0, row0 + rows). Defaults: the buffers are the whole image.
+    darks  : per frame a uint8 dark DN map covering the same rows as the frames, or None;
+             dark_min[i] = smallest hot DN (see dark_min_dn()).
+    flat, flat_std : flat-field value (uint8 DN or float64) and float64 uncertainty covering the
+             OUTPUT rows; ff_mean / ff_std_mean are the C ROI means (host floats).
+    """
+    n = len(frames)
+    if n == 0:
+        raise ValueError("merge needs at least one frame")
+    for i, f in enumerate(frames):
+        _require_cuda(f, f"frames[{i}]")
+    dev = frames[0].device
+    dt = frames[0].dtype
+    if dt not in (_U8, _F64):
+        raise TypeError(f"frames must be uint8 or float64, got {dt}")
+    shape = tuple(frames[0].shape)
+    if len(shape) != 3:
+        raise ValueError(f"frames must be (H, W, C), got shape {shape}")
+    keep: list = []
+    fr = []
+    for i, f in enumerate(frames):
+        if f.device != dev or f.dtype != dt or tuple(f.shape) != shape:
+            raise ValueError("all frames must share device, dtype and shape")
+        f = f.contiguous()
+        fr.append(f)
+    keep.extend(fr)
+    buf_rows, W, Cc = shape
+    height = buf_rows + buf_row0 if height is None else int(height)
+    rows = (buf_row0 + buf_rows - row0) if rows is None else int(rows)
+    if len(exposures) != n:
+        raise ValueError("one exposure per frame is required")
+    with_std = stds is not None
+    sd = []
+    if with_std:
+        if len(stds) != n:
+            raise ValueError("one std frame per value frame is required")
+        if icrf_diff is None:
+            raise ValueError("ICRF_diff is required to propagate uncertainty")
+        for i, s in enumerate(stds):
+            _require_cuda(s, f"stds[{i}]")
+            if tuple(s.shape) != shape:
+                raise ValueError("Value and std shapes must match.")
+            sd.append(s.to(_F64).contiguous())
+        keep.extend(sd)
+    icrf_t = _dev_f64(icrf, dev)
+    if tuple(icrf_t.shape) != (BITS, Cc):
+        raise ValueError(f"ICRF must have shape ({BITS}, {Cc}), got {tuple(icrf_t.shape)}")
+    diff_t = None
+    if icrf_diff is not None:
+        diff_t = _dev_f64(icrf_diff, dev)
+        if tuple(diff_t.shape) != (BITS, Cc):
+            raise ValueError(f"ICRF_diff must have shape ({BITS}, {Cc})")
+    w_lut, dw_lut = weight_luts(dev)
+    keep += [icrf_t, diff_t, w_lut, dw_lut]
+
+    a = nat.MergeArgs()
+    a.struct_size = C.sizeof(nat.MergeArgs)
+    a.n_frames, a.channels, a.variant = n, Cc, int(variant)
+    a.height, a.width, a.row0, a.rows, a.buf_row0, a.buf_rows = height, W, int(row0), rows, int(buf_row0), buf_rows
+    fptrs = _ptr_array(fr)
+    if dt == _U8:
+        a.frames_u8 = C.cast(fptrs, C.POINTER(C.c_void_p))
+    else:
+        a.frames_f64 = C.cast(fptrs, C.POINTER(C.c_void_p))
+    keep.append(fptrs)
+    if with_std:
+        sptrs = _ptr_array(sd)
+        a.stds = C.cast(sptrs, C.POINTER(C.c_void_p))
+        keep.append(sptrs)
+    exp = (C.c_double * n)(*[float(t) for t in exposures])
+    a.exposures = C.cast(exp, C.POINTER(C.c_double))
+    keep.append(exp)
+    a.icrf, a.icrf_diff = icrf_t.data_ptr(), nat.ptr(diff_t)
+    a.w_lut, a.dw_lut = w_lut.data_ptr(), dw_lut.data_ptr()
+    if darks is not None and any(d is not None for d in darks):
+        if len(darks) != n or dark_min is None or len(dark_min) != n:
+            raise ValueError("darks and dark_min need one entry per frame")
+        dk = []
+        for i, d in enumerate(darks):
+            if d is None:
+                dk.append(None)
+                continue
+            _require_cuda(d, f"darks[{i}]")
+            if d.dtype != _U8 or tuple(d.shape) != shape:
+                raise ValueError("dark maps must be uint8 with the frames' shape")
+            dk.append(d.contiguous())
+        dptrs = _ptr_array(dk)
+        dmin = (C.c_int32 * n)(*[int(x) for x in dark_min])
+        a.darks_u8 = C.cast(dptrs, C.POINTER(C.c_void_p))
+        a.dark_min_dn = C.cast(dmin, C.POINTER(C.c_int32))
+        a.median_k = int(median_k)
+        keep += [dk, dptrs, dmin]
+    out_shape = (rows, W, Cc)
+    if flat is not None:
+        _require_cuda(flat, "flat")
+        if tuple(flat.shape) != out_shape:
+            raise ValueError(f"flat field must cover the output rows: expected {out_shape}, got {tuple(flat.shape)}")
+        flat = flat.contiguous()
+        if flat.dtype == _U8:
+            a.flat_u8 = flat.data_ptr()
+        elif flat.dtype == _F64:
+            a.flat_f64 = flat.data_ptr()
+        else:
+            raise TypeError("flat must be uint8 or float64")
+        if ff_mean is None:
+            raise ValueError("ff_mean is required with a flat field")
+        for c in range(Cc):
+            a.ff_mean[c] = float(ff_mean[c])
+        keep.append(flat)
+        if with_std:
+            if flat_std is None or ff_std_mean is None:
+                raise ValueError("flat_std and ff_std_mean are required to propagate uncertainty through the flat field")
+            _require_cuda(flat_std, "flat_std")
+            flat_std = flat_std.to(_F64).contiguous()
+            if tuple(flat_std.shape) != out_shape:
+                raise ValueError("flat_std must cover the output rows")
+            a.flat_std = flat_std.data_ptr()
+            for c in range(Cc):
+                a.ff_std_mean[c] = float(ff_std_mean[c])
+            keep.append(flat_std)
+    outputs = {}
+    if want_val:
+        outputs["val"] = torch.empty(out_shape, dtype=_F64, device=dev)
+        a.out_val = outputs["val"].data_ptr()
+        if with_std:
+            outputs["std"] = torch.empty(out_shape, dtype=_F64, device=dev)
+            a.out_std = outputs["std"].data_ptr()
+    if want_sum_w:
+        outputs["sum_w"] = torch.empty(out_shape, dtype=_F64, device=dev)
+        a.out_sum_w = outputs["sum_w"].data_ptr()
+    return MergePlan(a, keep, dev, outputs)
+
+
+def merge(frames, exposures, icrf, icrf_diff=None, stds=None, **kw) -> dict:
+    """plan_merge(...).launch(); returns {'val', 'std'?, 'sum_w'?} device tensors."""
+    plan = plan_merge(frames, exposures, icrf, icrf_diff, stds, **kw)
+    plan.launch()
+    return plan.outputs
+
+
+def sum_of_weights(frames, darks=None, dark_min=None, median_k: int = 3, **kw):
+    """modules/exposure_series.py:317-345 -> (S, S**2) as device tensors."""
+    Cc = frames[0].shape[-1]
+    ident = np.zeros((BITS, Cc))
+    plan = plan_merge(frames, [1.0] * len(frames), ident, darks=darks, dark_min=dark_min, median_k=median_k,
+                      want_sum_w=True, want_val=False, **kw)
+    plan.launch()
+    S = plan.outputs["sum_w"]
+    return S, elementwise_binary(nat.HM_OP_MUL, S, None, S, None)[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# row 10: operators
+# ---------------------------------------------------------------------------------------------
+def _bcast_strides(t: torch.Tensor, shape) -> List[int]:
+    pad = len(shape) - t.dim()
+    st = [0] * pad + list(t.stride())
+    sh = [1] * pad + list(t.shape)
+    return [0 if sh[d] == 1 and shape[d] != 1 else st[d] for d in range(len(shape))]
+
+
+def elementwise_binary(op: int, x1: torch.Tensor, s1, x2: torch.Tensor, s2):
+    """modules/measurand.py:106-241 for two float64 device operands (NumPy broadcasting)."""
+    _require_cuda(x1, "x1")
+    _require_cuda(x2, "x2")
+    x1 = x1.to(_F64).contiguous()
+    x2 = x2.to(_F64).contiguous()
+    if s1 is not None:
+        s1 = s1.to(_F64).contiguous()
+    if s2 is not None:
+        s2 = s2.to(_F64).contiguous()
+    try:
+        shape = torch.broadcast_shapes(x1.shape, x2.shape)
+    except RuntimeError:
+        raise ValueError("Measurands are not broadcastable.")
+    if len(shape) > nat.HM_MAX_DIMS:
+        raise NotImplementedError(f"more than {nat.HM_MAX_DIMS} dimensions")
+    if len(shape) == 0:
+        shape = (1,)
+    nd = len(shape)
+    out = torch.empty(shape, dtype=_F64, device=x1.device)
+    with_std = s1 is not None or s2 is not None
+    out_std = torch.empty(shape, dtype=_F64, device=x1.device) if with_std else None
+    sh = (C.c_int64 * nd)(*shape)
+    st1 = (C.c_int64 * nd)(*_bcast_strides(x1, shape))
+    st2 = (C.c_int64 * nd)(*_bcast_strides(x2, shape))
+    with torch.cuda.device(x1.device):
+        nat.check(nat.lib.hm_binary_op(op, x1.data_ptr(), nat.ptr(s1), x2.data_ptr(), nat.ptr(s2), out.data_ptr(),
+                                       nat.ptr(out_std), nd, sh, st1, st2, _stream(x1.device)), "hm_binary_op")
+    return out, out_std
+
+
+def elementwise_unary(op: int, x: torch.Tensor, s):
+    _require_cuda(x, "x")
+    x = x.to(_F64).contiguous()
+    if s is not None:
+        s = s.to(_F64).contiguous()
+    out = torch.empty_like(x)
+    out_std = torch.empty_like(x) if s is not None else None
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.hm_unary_op(op, x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_std), x.numel(),
+                                      _stream(x.device)), "hm_unary_op")
+    return out, out_std

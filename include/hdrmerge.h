@@ -1,0 +1,202 @@
+/*
+ * hdrmerge.h - C ABI of the MI355X-native HDR-merge / linearization engine (libhdrmerge.so).
+ *
+ * This is the drop-in boundary for ONE path of samivout/camera_linearity: per-pixel ICRF-LUT
+ * linearization -> Gaussian-weighted HDR merge -> first-order uncertainty propagation, with
+ * dark-frame hot-pixel filtering and flat-field correction. The reference has no FFI of its own;
+ * its extension point is the array-backend protocol of AbstractMeasurand
+ * (modules/measurand.py:26-32, modules/cupy_measurand.py:28-39, modules/measurand_factory.py:10-14).
+ * A maintainer binds these entry points with ctypes from a third backend class next to
+ * NumpyMeasurand / CupyMeasurand; each declaration below cites the reference
+ * function whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) unless marked [host];
+ *     buffers are caller-owned, contiguous, and never retained after the call returns;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call is
+ *     asynchronous on that stream and performs no allocation and no host synchronisation, so it may
+ *     be captured in a hipGraph;
+ *   - images are row-major H x W x C with the channel innermost (OpenCV BGR order,
+ *     modules/global_settings.py:32); "n" counts ELEMENTS (H*W*C), element e has channel e % C;
+ *   - 8-bit frames are digital numbers (DN) 0..255; their value is DN / 255.0
+ *     (modules/image_set.py:223); BITS = 256, MAX_DN = 255 (modules/global_settings.py:35-37);
+ *   - return value: HM_OK (0) or a negative HM_E* code; nothing throws. hm_strerror() names it.
+ */
+#ifndef HDRMERGE_H
+#define HDRMERGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_ABI_VERSION 1
+#define HM_BITS 256
+#define HM_MAX_FRAMES 32     /* frames per fused merge launch */
+#define HM_MAX_CHANNELS 4
+
+enum {
+    HM_OK = 0,
+    HM_EINVAL = -1,        /* bad argument (null pointer, non-positive size, bad enum)        */
+    HM_EUNSUPPORTED = -2,  /* valid request this build cannot serve (N > HM_MAX_FRAMES, C > 4) */
+    HM_EALIGN = -3,        /* a float64 buffer is not 8-byte aligned                           */
+    HM_ELAUNCH = -4,       /* the HIP runtime rejected the launch (hipGetLastError != success) */
+    HM_ENODEVICE = -5,     /* no usable gfx950 device                                          */
+    HM_ESHAPE = -6         /* geometry inconsistent (tile outside image, halo too small, ...)  */
+};
+
+int hm_version(void);                 /* HM_ABI_VERSION of the loaded library          */
+const char* hm_strerror(int code);    /* static string, never NULL                     */
+int hm_device_info(int* n_devices, int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Row 3 - AbstractMeasurand.apply_gaussian_weight (modules/measurand.py:606-618)
+ *   w = e**(-30 (v-0.5)^2), dw = -60 (v-0.5) w.
+ * hm_gaussian_weight_f64 evaluates it analytically on float64 values; hm_gaussian_weight_u8 looks
+ * the DN up in the caller's 256-entry tables (bit-identical to NumPy when the caller built the
+ * tables with NumPy). Either output may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int hm_gaussian_weight_f64(const double* v, double* w, double* dw, int64_t n, void* stream);
+int hm_gaussian_weight_u8(const uint8_t* dn, const double* w_lut, const double* dw_lut,
+                          double* w, double* dw, int64_t n, void* stream);
+/* [host] helper for C callers: fills w_lut/dw_lut (256 each) with libm pow(); may differ from
+ * NumPy's `np.e ** x` in the last ulp. */
+int hm_gaussian_weight_lut_host(double* w_lut /*[host]*/, double* dw_lut /*[host]*/);
+
+/* ------------------------------------------------------------------------------------------
+ * Row 1 - ImageSet.load_value_image arithmetic (modules/image_set.py:223): out = dn / 255.0
+ * ------------------------------------------------------------------------------------------ */
+int hm_u8_to_unit_f64(const uint8_t* dn, double* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row 4 - AbstractMeasurand.linearize / _linearize_channel / _linearize_single
+ *         (modules/measurand.py:471-541)
+ *   idx  = dn                       (integer input, :505/:533)
+ *        = uint8(rint(v * 255))     (float input, round-half-even then wrap mod 256, :503/:531)
+ *   out_val[e] = icrf[idx[e] * lut_stride + (e % C) * (lut_stride > 1)]
+ *   out_std[e] = icrf_diff[...same...] * std[e]    only when std, icrf_diff and out_std are given
+ * icrf / icrf_diff are (256, C) row-major (lut_stride == C) or 1-D (256,) applied to every channel
+ * (lut_stride == 1, the `_linearize_single` form used by ImageSet.calculate_numerical_STD,
+ * modules/image_set.py:383). out_idx (nullable) exposes the uint8 index for the bit-exact check.
+ * ------------------------------------------------------------------------------------------ */
+int hm_linearize_u8(const uint8_t* dn, const double* std, const double* icrf, const double* icrf_diff,
+                    double* out_val, double* out_std, int64_t n, int C, int lut_stride, void* stream);
+int hm_linearize_f64(const double* v, const double* std, const double* icrf, const double* icrf_diff,
+                     double* out_val, double* out_std, uint8_t* out_idx,
+                     int64_t n, int C, int lut_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rows 5-9 fused - ExposureSeries._precalculate_sum_of_weights + _compute_HDR_image_set
+ * (modules/exposure_series.py:317-397) with the optional hot-pixel prologue
+ * (ImageSet.bad_pixel_filter -> filter_larger_than_by_map, modules/measurand.py:543-557) and the
+ * optional flat-field epilogue (normalize_by_map, modules/measurand.py:559-604).
+ *
+ *   S      = sum_i w(v_i)                                                       (:340)
+ *   val    = sum_i (w_i g_i) / (S t_i)                                          (:388)
+ *   var    = sum_i ( ((dw_i g_i + w_i dg_i)/S - (dw_i w_i g_i)/S^2) dg_i/t_i )^2 (:389)
+ *   std    = var ** (1/2)                                                       (:394)
+ * with v_i the frame value BEFORE linearization, g_i = icrf[idx_i, c], dg_i = icrf_diff[idx_i, c] * std_i.
+ * One launch reads every input byte once and writes every output byte once.
+ *
+ * Tiling: a call produces image rows [row0, row0 + rows) of an H x W x C image.
+ * Input frame / std / dark pointers address image row `buf_row0` (<= row0) and hold `buf_rows`
+ * rows, so a row-tile shard passes its slice plus the median halo; the median uses scipy 'reflect'
+ * only at the true image edges (0 and H). Output and flat pointers address row0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hm_merge_args {
+    uint32_t struct_size;         /* sizeof(hm_merge_args), for ABI evolution                       */
+    int32_t  n_frames;            /* N, 1..HM_MAX_FRAMES, ascending exposure                        */
+    int32_t  channels;            /* C, 1..HM_MAX_CHANNELS                                          */
+    int32_t  variant;             /* 0 = library default; >0 selects a tuning variant (bench only)  */
+    int64_t  height;              /* H of the full image                                            */
+    int64_t  width;               /* W                                                              */
+    int64_t  row0, rows;          /* output rows of this call                                       */
+    int64_t  buf_row0, buf_rows;  /* image rows covered by the input buffers                        */
+
+    const uint8_t* const* frames_u8;   /* [host] N device pointers to uint8 DN frames, or NULL       */
+    const double*  const* frames_f64;  /* [host] N device pointers to float64 value frames, or NULL  */
+    const double*  const* stds;        /* [host] N device pointers to float64 std frames, or NULL    */
+    const double*  exposures;          /* [host] N exposure times in seconds (features['exposure'])  */
+
+    const double* icrf;           /* (256, C) float64                                               */
+    const double* icrf_diff;      /* (256, C) float64; required when stds != NULL                   */
+    const double* w_lut;          /* (256,) weight table on the DN grid (u8 frames)                 */
+    const double* dw_lut;         /* (256,) weight derivative table (u8 frames with stds)           */
+
+    /* hot-pixel prologue: frame i is filtered where dark_u8[i][e] >= dark_min_dn[i]                 */
+    const uint8_t* const* darks_u8;    /* [host] N device pointers (NULL entries = no filter), or NULL */
+    const int32_t* dark_min_dn;        /* [host] N thresholds in DN (1..256)                         */
+    int32_t  median_k;            /* odd kernel size (gs.MEDIAN_FILTER_KERNEL_SIZE), 3..7           */
+    int32_t  _pad0;
+
+    /* flat-field epilogue (all NULL = off)                                                          */
+    const uint8_t* flat_u8;       /* flat value as DN (value = DN/255), or                          */
+    const double*  flat_f64;      /* flat value as float64                                          */
+    const double*  flat_std;      /* flat uncertainty, float64 (required when std output is on)     */
+    double ff_mean[HM_MAX_CHANNELS];     /* per-channel ROI mean of flat value  (measurand.py:582)  */
+    double ff_std_mean[HM_MAX_CHANNELS]; /* per-channel ROI mean of flat std    (measurand.py:583)  */
+
+    double* out_val;              /* rows x W x C float64, or NULL (sum-of-weights only)            */
+    double* out_std;              /* rows x W x C float64; required iff stds != NULL                */
+    double* out_sum_w;            /* optional S (rows x W x C), NULL to skip                        */
+} hm_merge_args;
+
+int hm_merge(const hm_merge_args* args /*[host]*/, void* stream);
+
+/* Algorithmic HBM bytes one hm_merge call moves: every input byte once, every output
+ * byte once, LUTs excluded. Used by bench.py for roofline.achieved. */
+int64_t hm_merge_algorithmic_bytes(const hm_merge_args* args /*[host]*/);
+
+/* ------------------------------------------------------------------------------------------
+ * Row 8 standalone - AbstractMeasurand.filter_larger_than_by_map (modules/measurand.py:543-557):
+ * out = where(map >= min / map > thr, median_kxk(x, axes=(0,1), mode='reflect'), x), one call per array
+ * (val: uint8 or float64; std: float64). map_f64 is compared with `> thr` in value units,
+ * map_u8 with `>= min_dn` in DN.
+ * ------------------------------------------------------------------------------------------ */
+int hm_hot_pixel_filter_u8(const uint8_t* x, const uint8_t* map_u8, const double* map_f64,
+                           int min_dn, double thr, int median_k, uint8_t* out,
+                           int64_t H, int64_t W, int C, void* stream);
+int hm_hot_pixel_filter_f64(const double* x, const uint8_t* map_u8, const double* map_f64,
+                            int min_dn, double thr, int median_k, double* out,
+                            int64_t H, int64_t W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row 9 standalone - flat-field ROI mean (modules/measurand.py:561-583) and normalize_by_map
+ * (modules/measurand.py:585-604).
+ * hm_roi_mean: per-channel mean over rows [x0,x1) x cols [y0,y1) of an H x W x C image, two-stage
+ * deterministic reduction; `workspace` needs hm_roi_mean_workspace_bytes() bytes; out_mean is C
+ * float64 on the device.
+ * ------------------------------------------------------------------------------------------ */
+size_t hm_roi_mean_workspace_bytes(void);
+int hm_roi_mean_u8(const uint8_t* img, int64_t H, int64_t W, int C,
+                   int64_t x0, int64_t x1, int64_t y0, int64_t y1,
+                   double* out_mean, void* workspace, void* stream);
+int hm_roi_mean_f64(const double* img, int64_t H, int64_t W, int C,
+                    int64_t x0, int64_t x1, int64_t y0, int64_t y1,
+                    double* out_mean, void* workspace, void* stream);
+int hm_normalize_by_map(const double* val, const double* std,
+                        const uint8_t* flat_u8, const double* flat_f64, const double* flat_std,
+                        const double* ff_mean /*[host] C*/, const double* ff_std_mean /*[host] C*/,
+                        double* out_val, double* out_std, int64_t n, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row 10 - Measurand operators with first-order uncertainty propagation
+ * (modules/measurand.py:106-279). Operands broadcast NumPy-style: `shape` is the broadcast result
+ * shape (ndim <= 6), strides are in ELEMENTS with 0 on broadcast axes. s1 / s2 may be NULL (treated
+ * as zeros, :121-124); out_std must be NULL iff both are NULL.
+ * ------------------------------------------------------------------------------------------ */
+enum { HM_OP_ADD = 0, HM_OP_SUB = 1, HM_OP_MUL = 2, HM_OP_DIV = 3, HM_OP_POW = 4 };
+enum { HM_UOP_NEG = 0, HM_UOP_LOG_E = 1, HM_UOP_LOG_10 = 2 };
+#define HM_MAX_DIMS 6
+int hm_binary_op(int op, const double* x1, const double* s1, const double* x2, const double* s2,
+                 double* out_val, double* out_std, int ndim, const int64_t* shape /*[host]*/,
+                 const int64_t* strides1 /*[host]*/, const int64_t* strides2 /*[host]*/, void* stream);
+int hm_unary_op(int op, const double* x, const double* s, double* out_val, double* out_std,
+                int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDRMERGE_H */

@@ -1,0 +1,259 @@
+"""GPU parity tests of the fused merge and its per-frame kernels, through the C ABI (libhdrmerge.so).
+
+Checker = oracle/hdr_oracle.py (NumPy restatement pinned against the reference, tests/test_oracle_golden.py)
+and the golden vectors produced by running the reference (tests/golden/*.npz).
+
+Tolerances (north_star: LUT index bit-exact, float64 radiance/uncertainty within 1e-6 relative):
+  index ............. exact
+  val (uint8 frames)  rtol 1e-12   (kernel sums w*g/t then divides by S; the reference divides per frame)
+  std ............... rtol 1e-9    (the A-term of exposure_series.py:389 cancels; 1/S multiplies replace divides)
+  float64 frames .... rtol 1e-11   (device exp() vs NumPy `np.e ** x`, <= few ulp)
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import hdr_oracle as orc  # noqa: E402
+
+VAL_RTOL, STD_RTOL, F64_RTOL = 1e-12, 1e-9, 1e-11
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from camera_linearity_amd import engine
+    return engine
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def close(a, b, rtol):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=0)
+
+
+# ------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("name", ["merge_identity", "merge_std", "merge_ramp"])
+def test_merge_golden_u8(eng, golden, name):
+    g = golden(name)
+    frames = [dev(f) for f in g["frames"]]
+    stds = [dev(s) for s in g["stds"]] if "stds" in g else None
+    out = eng.merge(frames, g["exposures"], g["icrf"], g["icrf_diff"], stds, want_sum_w=True)
+    close(host(out["sum_w"]), g["S"], 1e-15 * 8)
+    close(host(out["val"]), g["val"], VAL_RTOL)
+    if stds is not None:
+        close(host(out["std"]), g["std"], STD_RTOL)
+
+
+def test_merge_golden_float_frames(eng, golden):
+    g = golden("merge_float")
+    frames = [dev(f) for f in g["frames_f64"]]
+    stds = [dev(s) for s in g["stds"]]
+    out = eng.merge(frames, g["exposures"], g["icrf"], g["icrf_diff"], stds)
+    close(host(out["val"]), g["val"], F64_RTOL)
+    close(host(out["std"]), g["std"], STD_RTOL)
+
+
+def _dark_setup(eng, g, dark_arrays):
+    darks, mins = [], []
+    for t in g["exposures"]:
+        j, sc = orc.select_dark(float(t), [float(x) for x in g["dark_exposures"]], float(g["dark_threshold"]))
+        darks.append(None if j < 0 else dev(dark_arrays[j]))
+        mins.append(256 if j < 0 else eng.dark_min_dn(sc, float(g["dark_threshold"])))
+    return darks, mins
+
+
+def test_merge_golden_full_corrections(eng, golden):
+    g = golden("merge_full")
+    frames = [dev(f) for f in g["frames"]]
+    stds = [dev(s) for s in g["stds"]]
+    darks, mins = _dark_setup(eng, g, [g["dark16"], g["dark32"], g["dark64"]])
+    flat, flat_std = dev(g["flat"]), dev(g["flat_std"])
+    h, w = g["flat"].shape[:2]
+    x0, x1, y0, y1 = eng.flat_roi_bounds(h, w, float(g["ff_mid"]))
+    m = host(eng.roi_mean(flat, x0, x1, y0, y1))
+    s = host(eng.roi_mean(flat_std, x0, x1, y0, y1))
+    close(m, g["ff_mean"], 1e-14)
+    close(s, g["ff_std_mean"], 1e-14)
+    # hot-pixel filter only
+    out = eng.merge(frames, g["exposures"], g["icrf"], g["icrf_diff"], stds, darks=darks, dark_min=mins,
+                    median_k=int(g["median_k"]))
+    close(host(out["val"]), g["val"], VAL_RTOL)
+    close(host(out["std"]), g["std"], STD_RTOL)
+    # + flat field
+    out = eng.merge(frames, g["exposures"], g["icrf"], g["icrf_diff"], stds, darks=darks, dark_min=mins,
+                    median_k=int(g["median_k"]), flat=flat, flat_std=flat_std, ff_mean=m, ff_std_mean=s)
+    close(host(out["val"]), g["val_ff"], VAL_RTOL)
+    close(host(out["std"]), g["std_ff"], STD_RTOL)
+    # no corrections
+    out = eng.merge(frames, g["exposures"], g["icrf"], g["icrf_diff"], stds)
+    close(host(out["val"]), g["val_nohot"], VAL_RTOL)
+    close(host(out["std"]), g["std_nohot"], STD_RTOL)
+    # standalone normalize_by_map on the reference's merged image
+    nv, ns = eng.normalize_by_map(dev(g["val"]), dev(g["std"]), flat, flat_std, m, s)
+    close(host(nv), g["val_ff"], 1e-14)
+    close(host(ns), g["std_ff"], 1e-13)
+
+
+def test_merge_golden_scaled_darks(eng, golden):
+    g = golden("merge_dark_scaled")
+    frames = [dev(f) for f in g["frames"]]
+    stds = [dev(s) for s in g["stds"]]
+    darks, mins = _dark_setup(eng, g, list(g["darks"]))
+    out = eng.merge(frames, g["exposures"], g["icrf"], g["icrf_diff"], stds, darks=darks, dark_min=mins,
+                    median_k=int(g["median_k"]))
+    close(host(out["val"]), g["val"], VAL_RTOL)
+    close(host(out["std"]), g["std"], STD_RTOL)
+
+
+# ------------------------------------------------------------------ per-frame kernels
+def test_linearize_index_bit_exact_and_values(eng, golden):
+    g = golden("merge_float")
+    v = g["frames_f64"][0]
+    val, std, idx = eng.linearize(dev(v), dev(g["stds"][0]), g["icrf"], g["icrf_diff"], return_index=True)
+    assert np.array_equal(host(idx), g["idx"][0])             # bit-exact uint8 LUT index incl. .5 ties and wraps
+    assert np.array_equal(host(val), g["lin0_val"])           # a gather: exact
+    close(host(std), g["lin0_std"], 1e-15)
+    for i in (1, 2):
+        _, _, idx = eng.linearize(dev(g["frames_f64"][i]), None, g["icrf"], return_index=True)
+        assert np.array_equal(host(idx), g["idx"][i])
+
+
+def test_linearize_u8_and_single_channel_lut(eng, golden):
+    g = golden("merge_std")
+    f = g["frames"][1]
+    val, std = eng.linearize(dev(f), dev(g["stds"][1]), g["icrf"], g["icrf_diff"])
+    assert np.array_equal(host(val), g["lin1_val"])
+    close(host(std), g["lin1_std"], 1e-15)
+    # no ICRF_diff -> no std (measurand.py:498-500)
+    val2, std2 = eng.linearize(dev(f), dev(g["stds"][1]), g["icrf"])
+    assert std2 is None and np.array_equal(host(val2), g["lin1_val"])
+    # 1-D LUT applied to every channel (ImageSet.calculate_numerical_STD, image_set.py:383)
+    lut = np.linspace(0.001, 0.02, 256)
+    val3, _ = eng.linearize(dev(f), None, lut)
+    assert np.array_equal(host(val3), lut[f])
+    # float values on the DN grid give the same index as the DN itself
+    val4, _, idx4 = eng.linearize(dev(f.astype(np.float64) / 255), None, g["icrf"], return_index=True)
+    assert np.array_equal(host(idx4), f) and np.array_equal(host(val4), g["lin1_val"])
+
+
+def test_gaussian_weight(eng, golden):
+    g = golden("merge_float")
+    w, dw = eng.gaussian_weight(dev(g["frames_f64"][0]))
+    close(host(w), g["w0"], 1e-14)
+    close(host(dw), g["dw0"], 1e-14)
+    r = golden("merge_ramp")
+    dn = np.arange(256, dtype=np.uint8)
+    w, dw = eng.gaussian_weight(dev(dn))
+    assert np.array_equal(host(w), r["w_lut"]) and np.array_equal(host(dw), r["dw_lut"])   # LUT path: bit-identical
+    assert np.array_equal(host(eng.u8_to_unit(dev(dn))), dn.astype(np.float64) / 255)
+
+
+def test_hot_pixel_filter_standalone(eng):
+    rng = np.random.default_rng(11)
+    for (h, w, k) in ((9, 13, 3), (7, 5, 5), (3, 4, 3), (2, 2, 3)):
+        x = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+        xs = rng.random((h, w, 3))
+        dark = rng.integers(0, 40, size=(h, w, 3)).astype(np.uint8)
+        thr = 0.1
+        ref = orc.hot_pixel_filter(x.astype(np.float64), orc.unit_from_u8(dark), thr, k)
+        out = eng.hot_pixel_filter(dev(x), dev(dark), thr, k)
+        assert np.array_equal(host(out).astype(np.float64), ref)
+        refs = orc.hot_pixel_filter(xs, orc.unit_from_u8(dark), thr, k)
+        outs = eng.hot_pixel_filter(dev(xs), dev(orc.unit_from_u8(dark)), thr, k)
+        assert np.array_equal(host(outs), refs)
+
+
+# ------------------------------------------------------------------ seeded stacks vs the oracle
+@pytest.mark.parametrize("n,h,w", [(1, 5, 7), (2, 16, 16), (7, 33, 29), (7, 64, 128), (15, 24, 40), (16, 9, 11),
+                                   (17, 8, 8), (32, 4, 6)])
+@pytest.mark.parametrize("with_std", [False, True])
+def test_merge_vs_oracle_sizes(eng, n, h, w, with_std):
+    """Covers the fast kernel (N <= 16, whole 256/512-element groups), its tail, and the generic kernel
+    (N > 16, tiny images)."""
+    frames, stds, t = orc.synthetic_stack(100 + n, n, h, w, with_std=with_std)
+    icrf, diff = orc.synthetic_icrf()
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    out = eng.merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds] if with_std else None)
+    close(host(out["val"]), ref["val"], VAL_RTOL)
+    if with_std:
+        close(host(out["std"]), ref["std"], STD_RTOL)
+
+
+def test_merge_uniform_random_dn(eng):
+    """Uniform random DNs: worst case for LDS bank conflicts, every table entry exercised."""
+    rng = np.random.default_rng(5)
+    n, h, w = 7, 96, 128
+    frames = [rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(n)]
+    t = 1e-3 * 2.0 ** np.arange(n)
+    icrf, diff = orc.synthetic_icrf()
+    ref = orc.merge(frames, t, icrf, diff)
+    out = eng.merge([dev(f) for f in frames], t, icrf, diff)
+    close(host(out["val"]), ref["val"], VAL_RTOL)
+
+
+def test_merge_row_tiles_with_halo(eng):
+    """row tiles with a median halo reproduce the whole-image result exactly."""
+    rng = np.random.default_rng(9)
+    n, h, w = 5, 37, 24
+    frames, stds, t = orc.synthetic_stack(9, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    dark = rng.integers(0, 30, size=(h, w, 3)).astype(np.uint8)
+    dark[0, 0, 0] = 255
+    dark[h - 1, w - 1, 2] = 255
+    darks = [None, None, dark, dark, dark]
+    mins = [256, 256, 20, 20, 20]
+    whole = eng.merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds],
+                      darks=[None if d is None else dev(d) for d in darks], dark_min=mins, median_k=3)
+    ref = orc.merge(frames, t, icrf, diff, stds=stds,
+                    darks=[None if d is None else orc.unit_from_u8(d) for d in darks], dark_threshold=19.5 / 255, median_k=3)
+    close(host(whole["val"]), ref["val"], VAL_RTOL)
+    close(host(whole["std"]), ref["std"], STD_RTOL)
+    bounds = [0, 10, 11, 25, 37]
+    val = np.empty((h, w, 3))
+    std = np.empty((h, w, 3))
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        b0, b1 = max(0, r0 - 1), min(h, r1 + 1)
+        sl = slice(b0, b1)
+        out = eng.merge([dev(f[sl]) for f in frames], t, icrf, diff, [dev(s[sl]) for s in stds],
+                        darks=[None if d is None else dev(d[sl]) for d in darks], dark_min=mins, median_k=3,
+                        height=h, row0=r0, rows=r1 - r0, buf_row0=b0)
+        val[r0:r1] = host(out["val"])
+        std[r0:r1] = host(out["std"])
+    assert np.array_equal(val, host(whole["val"]))
+    assert np.array_equal(std, host(whole["std"]))
+
+
+def test_merge_argument_errors(eng):
+    f = dev(np.zeros((4, 4, 3), np.uint8))
+    icrf, diff = orc.synthetic_icrf()
+    with pytest.raises(ValueError):
+        eng.merge([f], [0.0], icrf)                               # non-positive exposure
+    with pytest.raises(ValueError):
+        eng.merge([f, f], [1.0], icrf)                            # exposures length
+    with pytest.raises(ValueError):
+        eng.merge([f], [1.0], icrf[:, :2])                        # ICRF shape
+    with pytest.raises(ValueError):
+        eng.merge([f], [1.0], icrf, None, [dev(np.zeros((4, 4, 3)))])   # std without ICRF_diff
+    with pytest.raises(NotImplementedError):
+        eng.merge([f] * 33, [1.0] * 33, icrf)                     # > HM_MAX_FRAMES
+    with pytest.raises(RuntimeError):
+        eng.merge([torch.zeros((4, 4, 3), dtype=torch.uint8)], [1.0], icrf)   # host tensor: no CPU fallback
+    d = dev(np.zeros((4, 4, 3), np.uint8))
+    with pytest.raises(ValueError):                               # halo missing for the median
+        eng.merge([f], [1.0], icrf, darks=[d], dark_min=[1], median_k=3, height=8, row0=2, rows=4, buf_row0=2)
+
+
+def test_sum_of_weights(eng, golden):
+    g = golden("merge_std")
+    S, S2 = eng.sum_of_weights([dev(f) for f in g["frames"]])
+    close(host(S), g["S"], 1e-15 * 8)
+    close(host(S2), g["S"] ** 2, 1e-14)
