@@ -154,13 +154,17 @@ __global__ __launch_bounds__(256) void merge_generic(const MergeK a) {
                 }
                 w = t_w[dn];
             }
-            S += w;
+            S = (i == 0) ? w : S + w;
         }
         if (a.out_sum_w) a.out_sum_w[e] = S;
         if (!a.out_val) continue;
-        const double S2 = S * S;                 // exposure_series.py:343
+        // Same operation sequence as merge_u8_fast, so a result does not depend on which kernel (or
+        // which tiling) produced it: reciprocals of S and S**2 (exposure_series.py:343) are formed once,
+        // the numerator of :388 is accumulated with fma and divided by S at the end.
+        const double invS = 1.0 / S;
+        const double invS2 = 1.0 / (S * S);
         // ---- pass 2: exposure_series.py:382-389 ----
-        double val = 0.0, var = 0.0;
+        double acc = 0.0, var = 0.0;
         for (int i = 0; i < N; ++i) {
             bool hot = false;
             if (HOT && a.dark[i]) hot = a.dark[i][ei] >= a.dark_min[i];
@@ -185,19 +189,20 @@ __global__ __launch_bounds__(256) void merge_generic(const MergeK a) {
                 dw = STD ? t_dw[dn] : 0.0;
             }
             const double g = t_g[idx * C + c];
-            const double t = a.inv_t[i];                       // holds 1/t_i
-            val += (w * g) * t;
+            const double it = a.inv_t[i];
+            const double wg = w * g;
+            acc = (i == 0) ? wg * it : fma(wg, it, acc);               // :388 numerator
             if (STD) {
                 double s = a.sd[i][ei];
                 if (HOT && hot) s = median_at(a.sd[i], a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                const double dg = t_d[idx * C + c] * s;        // measurand.py:512
-                const double A = (dw * g + w * dg) / S - ((dw * w) * g) / S2;
-                const double term = (A * dg) * t;
-                var += term * term;
+                const double dg = t_d[idx * C + c] * s;                // measurand.py:512
+                const double A = (dw * g + w * dg) * invS - ((dw * w) * g) * invS2;   // :389
+                const double term = (A * dg) * it;
+                var = (i == 0) ? term * term : fma(term, term, var);
             }
         }
-        val = val / S;
-        double sd = STD ? sqrt(var) : 0.0;
+        double val = acc / S;
+        double sd = STD ? sqrt(var) : 0.0;                             // :394
         if (a.has_flat) flat_field_apply(a, e, c, STD, val, sd);
         a.out_val[e] = val;
         if (STD) a.out_std[e] = sd;
@@ -227,7 +232,7 @@ template <> struct TabInfo<TAB_FUSED>  { static constexpr int bytes = 16 * 768; 
 template <> struct TabInfo<TAB_REP16>  { static constexpr int bytes = 128 * 256 + 128 * 768; };
 template <> struct TabInfo<TAB_REP32W> { static constexpr int bytes = 256 * 256 + 128 * 768; };
 template <> struct TabInfo<TAB_FUSED8> { static constexpr int bytes = 128 * 768; };
-template <> struct TabInfo<TAB_NONE>   { static constexpr int bytes = 64; };
+template <> struct TabInfo<TAB_NONE>   { static constexpr int bytes = 0; };
 constexpr int kStdTabBytes = 16 * 256 + 16 * 768;
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -238,6 +243,26 @@ __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {
 __device__ __forceinline__ void store2(double* p, double x, double y) {
     f64x2 v; v.x = x; v.y = y;
     __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(p));
+}
+
+// Coalesced output: lane l of a sub-unit holds elements 4l..4l+3 (32 contiguous output bytes), which as
+// a direct store is a 32-byte-stride pattern - measured 149 us vs 125 us for the same traffic with
+// fully contiguous 1 KB store instructions (tools/membench.hip). So the 4 values go through a
+// wave-private 2 KB LDS slab: written as [lane][4], read back as [k][lane][2], then two
+// global_store_dwordx4 that each cover 1 KB. DS operations of one wave execute in issue order, so no
+// barrier is needed; the wave_barrier only pins the compiler's ordering.
+__device__ __forceinline__ void store4_coalesced(char* slab, uint32_t lane, double* out_sub,
+                                                 double v0, double v1, double v2, double v3) {
+    f64x2 a, b;
+    a.x = v0; a.y = v1; b.x = v2; b.y = v3;
+    *reinterpret_cast<f64x2*>(slab + lane * 32u) = a;
+    *reinterpret_cast<f64x2*>(slab + lane * 32u + 16u) = b;
+    __builtin_amdgcn_wave_barrier();
+    const f64x2 lo = *reinterpret_cast<const f64x2*>(slab + lane * 16u);
+    const f64x2 hi = *reinterpret_cast<const f64x2*>(slab + 1024u + lane * 16u);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_nontemporal_store(lo, reinterpret_cast<f64x2*>(out_sub + 2u * lane));
+    __builtin_nontemporal_store(hi, reinterpret_cast<f64x2*>(out_sub + 128u + 2u * lane));
 }
 
 // fill the val-only tables; blockDim-agnostic
@@ -355,6 +380,7 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / GROUP);
     const uint32_t gstride = gridDim.x * WPB;
     const uint32_t woff = lane_woff<TAB>();
+    char* slab = lds + (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + wave * 2048u;   // wave-private transpose slab
 
     uint32_t g = blockIdx.x * WPB + wave;                                   // wave-uniform
     uint32_t raw[NF][U];
@@ -386,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
         for (int s = 0; s < U; ++s) {
             const int64_t sbase = gbase + 256 * s;                          // scalar
             const int64_t e0 = sbase + lane4;
-            const int64_t ei0 = a.in_off + e0;
+            const int64_t ei0 = a.in_off + e0; (void)ei0;
             const uint32_t c0 = (g * U + s + lane) % 3u;
 
             // hot-pixel prologue (rare): replace the DN by the k x k median of its frame
@@ -457,10 +483,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                             flat_field_apply(a, e0 + j, static_cast<int>((c0 + j) % 3u), false, val[j], dummy);
                         }
                     }
-                    if (osw) { store2(osw + lane4, S[0], S[1]); store2(osw + lane4 + 2, S[2], S[3]); }
+                    if (osw) store4_coalesced(slab, lane, osw, S[0], S[1], S[2], S[3]);
                 }
-                store2(ov + lane4, val[0], val[1]);
-                store2(ov + lane4 + 2, val[2], val[3]);
+                store4_coalesced(slab, lane, ov, val[0], val[1], val[2], val[3]);
             } else {
                 const double2* t_wdw = reinterpret_cast<const double2*>(lds);
                 const char* t_gd = lds + 16 * 256;
@@ -524,7 +549,7 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 double val[4], so[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    val[j] = acc[j] * invS[j];
+                    val[j] = acc[j] / S[j];
                     so[j] = sqrt(var[j]);                                                        // :394
                 }
                 if constexpr (EXTRAS) {
@@ -533,13 +558,10 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                         for (int j = 0; j < 4; ++j)
                             flat_field_apply(a, e0 + j, static_cast<int>((c0 + j) % 3u), true, val[j], so[j]);
                     }
-                    if (osw) { store2(osw + lane4, S[0], S[1]); store2(osw + lane4 + 2, S[2], S[3]); }
+                    if (osw) store4_coalesced(slab, lane, osw, S[0], S[1], S[2], S[3]);
                 }
-                double* os = a.out_std + sbase;
-                store2(ov + lane4, val[0], val[1]);
-                store2(ov + lane4 + 2, val[2], val[3]);
-                store2(os + lane4, so[0], so[1]);
-                store2(os + lane4 + 2, so[2], so[3]);
+                store4_coalesced(slab, lane, ov, val[0], val[1], val[2], val[3]);
+                store4_coalesced(slab, lane, a.out_std + sbase, so[0], so[1], so[2], so[3]);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep one sub-unit's gathers from piling onto the next one's
         }
@@ -568,7 +590,7 @@ struct FastCfg { int tab, u, prefetch, block; };
 
 static FastCfg default_cfg(bool with_std) {
     if (with_std) return FastCfg{TAB_PLAIN, 1, 0, 256};
-    return FastCfg{TAB_REP16, 2, 1, 1024};
+    return FastCfg{TAB_FUSED, 2, 0, 256};     // tools/tune_merge.py, profiles/r01_tune_merge.json
 }
 
 static bool decode_variant(int variant, bool with_std, FastCfg& c) {
@@ -582,7 +604,8 @@ static bool decode_variant(int variant, bool with_std, FastCfg& c) {
 
 template <int NF, int U, int TAB, bool STD, bool HOT, bool PF, bool EXTRAS, int BLOCK>
 static int launch_one(const MergeK& k, hipStream_t st) {
-    constexpr int lds = STD ? kStdTabBytes : TabInfo<TAB>::bytes;
+    constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + (BLOCK / 64) * 2048;   // tables + transpose slabs
+    static_assert(lds <= kMaxLds, "LDS budget");
     auto kernel = merge_u8_fast<NF, U, TAB, STD, HOT, PF, EXTRAS, BLOCK>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -616,7 +639,6 @@ static int launch_val_tab(const MergeK& k, const FastCfg& c, hipStream_t st) {
         case TAB_PLAIN:  return launch_val_blk<NF, U, TAB_PLAIN, PF>(k, c, st);
         case TAB_FUSED:  return launch_val_blk<NF, U, TAB_FUSED, PF>(k, c, st);
         case TAB_REP16:  return launch_val_blk<NF, U, TAB_REP16, PF>(k, c, st);
-        case TAB_REP32W: return launch_val_blk<NF, U, TAB_REP32W, PF>(k, c, st);
         case TAB_FUSED8: return launch_val_blk<NF, U, TAB_FUSED8, PF>(k, c, st);
         default:         return launch_val_blk<NF, U, TAB_NONE, PF>(k, c, st);
     }
@@ -630,8 +652,8 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, bool
         if (extras) return launch_one<NF, 1, TAB_PLAIN, true, false, false, true, 256>(k, st);
         return launch_one<NF, 1, TAB_PLAIN, true, false, false, false, 256>(k, st);
     }
-    if (hot) return launch_one<NF, 2, TAB_REP16, false, true, true, true, 1024>(k, st);
-    if (extras) return launch_one<NF, 2, TAB_REP16, false, false, true, true, 1024>(k, st);
+    if (hot) return launch_one<NF, 2, TAB_FUSED, false, true, false, true, 256>(k, st);
+    if (extras) return launch_one<NF, 2, TAB_FUSED, false, false, false, true, 256>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
         if (c.prefetch) {
             if (c.u == 1) return launch_val_tab<NF, 1, true>(k, c, st);
@@ -642,7 +664,7 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, bool
         if (c.u == 2) return launch_val_tab<NF, 2, false>(k, c, st);
         return launch_val_tab<NF, 4, false>(k, c, st);
     } else {
-        return launch_one<NF, 2, TAB_REP16, false, false, true, false, 1024>(k, st);
+        return launch_one<NF, 2, TAB_FUSED, false, false, false, false, 256>(k, st);
     }
 }
 

@@ -1,0 +1,411 @@
+"""HipMeasurand - the MI355X backend of the reference's Measurand protocol.
+
+Mirror of AbstractMeasurand / NumpyMeasurand / CupyMeasurand (modules/measurand.py:26-761,
+modules/cupy_measurand.py:28-137): a value array and an uncertainty array of the same shape, with
+operators that propagate uncertainty to first order. Same method names, argument meaning and error
+behaviour; the arrays are torch tensors resident in HBM and every hot-path method launches a
+hand-written HIP kernel through the C ABI (engine.py -> libhdrmerge.so). There is no CPU fallback.
+
+Differences from the reference, all from SURVEY.md 3.4 (the reference's multi-channel path does not
+run as written):
+  A/B  linearize on (..., C) data returns (..., C): out[..., c] = ICRF[idx[..., c], c]; `channels` is
+       arange(shape[-1]) and is set by the constructor too.
+  F    filter_larger_than_by_map replaces the masked pixels by the k x k median ('reflect').
+  H    normalize_by_map uses the integer ROI.
+Extra: `val` may be a uint8 DN tensor (the reference accepts integer arrays in linearize,
+measurand.py:505); `HipMeasurand.from_dn()` keeps an 8-bit frame as DNs in HBM (1 byte/element
+instead of 8) and materialises DN/255 (modules/image_set.py:223) only when `.val` is read.
+
+Rows "next" of SURVEY.md 8f (apply_thresholds, compute_dimension_statistics,
+compute_channel_histogram, compute_difference, interpolate, extract) are not hot-path kernels yet:
+they run as torch device ops on the same tensors so that the class surface is complete.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import settings as gs
+
+ScalarType = Union[int, float]
+_F64 = torch.float64
+_U8 = torch.uint8
+
+
+def is_broadcastable(shape1, shape2) -> bool:
+    """modules/general_functions.py:14-24."""
+    if not shape1 or not shape2:
+        raise ValueError("Shapes cannot be empty")
+    for a, b in zip(tuple(shape1)[::-1], tuple(shape2)[::-1]):
+        if not (a == 1 or b == 1 or a == b):
+            return False
+    return True
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _engine():
+    from . import engine          # imports _native: raises ImportError when libhdrmerge.so is missing
+    return engine
+
+
+class AbstractMeasurand:
+    """Backend protocol (modules/measurand.py:26-32): subclasses define lib, backend, ArrayType, InputType."""
+    lib = None
+    backend = None
+    fn_median_filter = None
+    ArrayType = None
+    InputType = None
+
+
+class HipMeasurand(AbstractMeasurand):
+    lib = torch
+    backend = "hip"
+    ArrayType = torch.Tensor
+    InputType = (int, float, torch.Tensor, np.ndarray)
+
+    # ---------------------------------------------------------------- construction
+    def __init__(self, val=None, std=None):
+        """modules/measurand.py:695-714: scalars become shape-(1,) float64 arrays; shapes must match.
+        NumPy arrays are uploaded silently, as CupyMeasurand does (modules/cupy_measurand.py:66-73)."""
+        if val is not None and not isinstance(val, self.InputType) or isinstance(val, bool):
+            raise TypeError("Invalid value type.")
+        if std is not None and not isinstance(std, self.InputType) or isinstance(std, bool):
+            raise TypeError("Invalid std type")
+        self._dn = None
+        self._val = self._to_tensor(val)
+        self._std = self._to_tensor(std, like=self._val)
+        if self._val is not None and self._std is not None and self._val.shape != self._std.shape:
+            raise ValueError("Value and std shapes must match.")
+        self._channels = None
+        self._update_channels()
+        self._initialized = True
+
+    @classmethod
+    def from_dn(cls, dn: torch.Tensor, std=None) -> "HipMeasurand":
+        """An 8-bit frame kept as uint8 DNs in HBM; `.val` is DN / MAX_DN on demand (image_set.py:223)."""
+        if isinstance(dn, np.ndarray):
+            dn = torch.as_tensor(np.ascontiguousarray(dn), device=default_device())
+        if not isinstance(dn, torch.Tensor) or dn.dtype != _U8:
+            raise TypeError("from_dn expects a uint8 array")
+        m = cls(None, None)
+        m._dn = dn
+        m._std = m._to_tensor(std, like=dn)
+        if m._std is not None and m._std.shape != dn.shape:
+            raise ValueError("Value and std shapes must match.")
+        m._update_channels()
+        return m
+
+    @staticmethod
+    def _to_tensor(x, like: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        if x is None:
+            return None
+        dev = like.device if like is not None else default_device()
+        if isinstance(x, (int, float)):
+            return torch.tensor([x], dtype=_F64, device=dev)
+        if isinstance(x, np.ndarray):
+            return torch.as_tensor(np.ascontiguousarray(x), device=dev)
+        return x
+
+    def _update_channels(self):
+        ref = self._val if self._val is not None else self._dn
+        if ref is None or ref.dim() == 0:
+            self._channels = None
+        else:
+            self._channels = torch.arange(ref.shape[-1], device=ref.device)       # deviation B
+
+    # ---------------------------------------------------------------- properties (measurand.py:49-84)
+    @property
+    def val(self):
+        if self._val is None and self._dn is not None:
+            self._val = _engine().u8_to_unit(self._dn)
+        return self._val
+
+    @val.setter
+    def val(self, value):
+        if value is not None and not isinstance(value, (torch.Tensor, np.ndarray)):
+            raise TypeError(f"val must be an array or None, got {type(value)} instead.")
+        self._dn = None
+        self._val = self._to_tensor(value, like=self._std)
+        self._update_channels()
+
+    @property
+    def dn(self) -> Optional[torch.Tensor]:
+        """uint8 DNs when the frame is 8-bit sourced (from_dn, or a uint8 `val`), else None."""
+        if self._dn is not None:
+            return self._dn
+        if self._val is not None and self._val.dtype == _U8:
+            return self._val
+        return None
+
+    @property
+    def std(self):
+        return self._std
+
+    @std.setter
+    def std(self, value):
+        if value is not None and not isinstance(value, (torch.Tensor, np.ndarray)):
+            raise TypeError(f"std must be an array or None, got {type(value)} instead.")
+        ref = self._val if self._val is not None else self._dn
+        self._std = self._to_tensor(value, like=ref)
+
+    @property
+    def channels(self):
+        return self._channels
+
+    @channels.setter
+    def channels(self, new_channels):
+        raise AttributeError("Channels is a read-only attribute, based on the shape of val array.")
+
+    @property
+    def shape(self):
+        ref = self._val if self._val is not None else self._dn
+        return None if ref is None else tuple(ref.shape)
+
+    def __repr__(self):
+        value_shape = self.shape if self.shape is not None else "None"
+        std_shape = tuple(self.std.shape) if self.std is not None else "None"
+        return f"Measurand(backend=hip, value.shape= {value_shape}, std.shape= {std_shape})"
+
+    def __copy__(self):
+        m = self.__class__(self._val, self._std)
+        m._dn = self._dn
+        m._update_channels()
+        return m
+
+    def __deepcopy__(self, memo):
+        m = self.__class__(None if self._val is None else self._val.clone(), None if self._std is None else self._std.clone())
+        m._dn = None if self._dn is None else self._dn.clone()
+        m._update_channels()
+        memo[id(self)] = m
+        return m
+
+    def to_numpy(self):
+        """(val, std) as NumPy arrays on the host (D2H copy)."""
+        v = self.val
+        return (None if v is None else v.cpu().numpy()), (None if self._std is None else self._std.cpu().numpy())
+
+    # ---------------------------------------------------------------- operators (measurand.py:106-302)
+    def _normalize_input(self, other):
+        """modules/measurand.py:281-302."""
+        if isinstance(other, self.__class__):
+            normalized_other = other
+        elif isinstance(other, self.InputType) and not isinstance(other, bool):
+            like = self._val if self._val is not None else self._dn
+            normalized_other = self.__class__(self._to_tensor(other, like=like))
+        else:
+            raise TypeError("Invalid other type.")
+        use_std = self.std is not None or normalized_other.std is not None
+        return normalized_other, use_std
+
+    def _f64(self):
+        v = self.val
+        return v if v.dtype == _F64 else v.to(_F64)
+
+    def _binary(self, other, op):
+        from ._native import HM_OP_ADD  # noqa: F401  (fail early and loudly without the library)
+        normalized_other, use_std = self._normalize_input(other)
+        x1, x2 = self._f64(), normalized_other._f64()
+        if not is_broadcastable(x1.shape, x2.shape):
+            raise ValueError("Measurands are not broadcastable.")
+        s1 = self.std if use_std else None
+        s2 = normalized_other.std if use_std else None
+        if x2.device != x1.device:
+            x2 = x2.to(x1.device)
+            s2 = None if s2 is None else s2.to(x1.device)
+        val, std = _engine().elementwise_binary(op, x1, s1, x2, s2)
+        return self.__class__(val, std)
+
+    def __add__(self, other):
+        from ._native import HM_OP_ADD
+        return self._binary(other, HM_OP_ADD)
+
+    def __sub__(self, other):
+        from ._native import HM_OP_SUB
+        return self._binary(other, HM_OP_SUB)
+
+    def __mul__(self, other):
+        from ._native import HM_OP_MUL
+        return self._binary(other, HM_OP_MUL)
+
+    def __rmul__(self, other):
+        """modules/measurand.py:213-215: `self * Measurand(other)`."""
+        return self * self.__class__(self._to_tensor(other, like=self._val if self._val is not None else self._dn))
+
+    def __truediv__(self, other):
+        from ._native import HM_OP_DIV
+        return self._binary(other, HM_OP_DIV)
+
+    def __pow__(self, other):
+        from ._native import HM_OP_POW
+        return self._binary(other, HM_OP_POW)
+
+    def _unary(self, op):
+        val, std = _engine().elementwise_unary(op, self._f64(), self.std)
+        return self.__class__(val, std)
+
+    def __neg__(self):
+        from ._native import HM_UOP_NEG
+        return self._unary(HM_UOP_NEG)
+
+    def log_e(self):
+        from ._native import HM_UOP_LOG_E
+        return self._unary(HM_UOP_LOG_E)
+
+    def log_10(self):
+        from ._native import HM_UOP_LOG_10
+        return self._unary(HM_UOP_LOG_10)
+
+    def zeros_like_measurand(self):
+        """modules/measurand.py:304-316."""
+        ref = self._val if self._val is not None else self._dn
+        new_val = None if ref is None else torch.zeros(ref.shape, dtype=_F64, device=ref.device)
+        new_std = None if self.std is None else torch.zeros_like(self.std)
+        return self.__class__(new_val, new_std)
+
+    # ---------------------------------------------------------------- hot path
+    def linearize(self, ICRF, ICRF_diff=None):
+        """modules/measurand.py:471-541 -> new Measurand with the ICRF-mapped values (and ICRF_diff * std)."""
+        src = self.dn if self.dn is not None else self.val
+        val, std = _engine().linearize(src, self.std, ICRF, ICRF_diff)
+        return self.__class__(val, std)
+
+    def lut_index(self):
+        """The uint8 LUT index linearize uses (measurand.py:503/505) - exposed for the bit-exact check."""
+        if self.dn is not None:
+            return self.dn.clone()
+        ident = np.zeros((gs.BITS,), dtype=np.float64)
+        return _engine().linearize(self.val, None, ident, return_index=True)[2]
+
+    def apply_gaussian_weight(self):
+        """modules/measurand.py:606-618 -> (y, dydx) arrays."""
+        src = self.dn if self.dn is not None else self.val
+        return _engine().gaussian_weight(src)
+
+    def filter_larger_than_by_map(self, map: "HipMeasurand", threshold_value: float):
+        """modules/measurand.py:543-557 (intended semantics, deviation F)."""
+        eng = _engine()
+        k = gs.MEDIAN_FILTER_KERNEL_SIZE
+        dmap = map.dn if map.dn is not None else map.val
+        src = self.dn if self.dn is not None else self.val
+        new_val = eng.hot_pixel_filter(src, dmap, threshold_value, k)
+        new_std = None if self.std is None else eng.hot_pixel_filter(self.std, dmap, threshold_value, k)
+        if new_val.dtype == _U8:
+            return self.__class__.from_dn(new_val, new_std)
+        return self.__class__(new_val, new_std)
+
+    def normalize_by_map(self, map: "HipMeasurand"):
+        """modules/measurand.py:559-604 (integer ROI, deviation H). ROI size from gs.IM_SIZE_X/Y or the map."""
+        eng = _engine()
+        fval = map.dn if map.dn is not None else map.val
+        size_x = gs.IM_SIZE_X or fval.shape[0]
+        size_y = gs.IM_SIZE_Y or fval.shape[1]
+        x0, x1, y0, y1 = eng.flat_roi_bounds(size_x, size_y, gs.FF_MID_PERCENTAGE)
+        means = eng.roi_mean(fval, x0, x1, y0, y1).cpu().numpy()
+        std_means = None
+        if self.std is not None:
+            if map.std is None:
+                raise ValueError("flat field needs a std image to propagate uncertainty")
+            std_means = eng.roi_mean(map.std, x0, x1, y0, y1).cpu().numpy()
+        val, std = eng.normalize_by_map(self._f64(), self.std, fval, map.std, means, std_means)
+        return self.__class__(val, std)
+
+    # ---------------------------------------------------------------- "next" rows (torch device ops)
+    def extract(self, dims=None, axis: Optional[int] = None):
+        """modules/measurand.py:352-373."""
+        target = [dims] if type(dims) is int else dims
+        idx = torch.as_tensor(target, device=self.val.device)
+        value = torch.index_select(self.val, axis if axis is not None else 0, idx)
+        std = None if self.std is None else torch.index_select(self.std, axis if axis is not None else 0, idx)
+        return self.__class__(value, std)
+
+    def apply_thresholds(self, lower: Optional[List] = None, upper: Optional[List] = None):
+        """modules/measurand.py:375-428 (in place)."""
+        value = self._f64()
+        n = value.shape[-1]
+        lower = [None] * n if lower is None else lower
+        upper = [None] * n if upper is None else upper
+        if len(lower) != n or len(upper) != n:
+            raise ValueError("The length of 'lower' and 'upper' must match the size of the independent axis.")
+        lo = torch.tensor([l if l is not None else -math.inf for l in lower], dtype=_F64, device=value.device)
+        hi = torch.tensor([u if u is not None else math.inf for u in upper], dtype=_F64, device=value.device)
+        mask = (value < lo) | (value > hi)
+        value = value.clone() if value is self._val else value
+        value[mask] = math.nan
+        self.val = value
+        if self.std is not None:
+            self._std[mask] = math.nan
+
+    def compute_dimension_statistics(self, axis=None):
+        """modules/measurand.py:318-350."""
+        values = self._f64()
+        if self.std is None:
+            mean = torch.nanmean(values, dim=axis) if axis is not None else torch.nanmean(values)
+            cnt = (~torch.isnan(values)).sum(dim=axis) if axis is not None else (~torch.isnan(values)).sum()
+            dev = torch.nan_to_num(values - (mean if axis is None else mean.reshape(_keep(values, axis))), nan=0.0)
+            sd = torch.sqrt((dev ** 2).sum(dim=axis) / cnt) if axis is not None else torch.sqrt((dev ** 2).sum() / cnt)
+            return {"mean": mean, "std": sd, "error": None}
+        weights = 1 / self.std
+        kw = {} if axis is None else {"dim": axis}
+        sw = torch.nansum(weights, **kw)
+        mean = torch.nansum(values * weights, **kw) / sw
+        mb = mean if axis is None else mean.reshape(_keep(values, axis))
+        sd = torch.sqrt(torch.nansum(weights * (values - mb) ** 2, **kw) / sw)
+        err = torch.nanmean(self.std, **kw)
+        return {"mean": mean, "std": sd, "error": err}
+
+    def compute_channel_histogram(self, bins: int, included_range=None, channels=None, use_std: bool = False):
+        """modules/measurand.py:430-469 (histograms are evaluated on the host)."""
+        if channels is None:
+            channels = list(range(gs.NUM_OF_CHS))
+        v, s = self.to_numpy()
+        out = {}
+        for c in channels:
+            cv = v[..., c]
+            mask = np.isfinite(cv)
+            weights = None
+            if use_std:
+                sc = s[..., c]
+                mask = np.logical_and(mask, sc != 0)
+                weights = 1 / sc[mask]
+            out[c] = np.histogram(cv[mask], bins=bins, range=included_range, weights=weights)
+        return out
+
+    @staticmethod
+    def compute_difference(x: "HipMeasurand", y: "HipMeasurand", multiplier: float):
+        """modules/measurand.py:620-655."""
+        cls = x.__class__
+        xv, yv = x._f64(), y._f64()
+        scale = multiplier * yv
+        abs_diff = xv - scale
+        rel_diff = abs_diff / scale
+        if x.std is None and y.std is None:
+            return cls(abs_diff, None), cls(rel_diff, None)
+        xs = 0 if x.std is None else x.std
+        ys = 0 if y.std is None else y.std
+        abs_std = torch.sqrt(xs ** 2 + (multiplier * ys) ** 2)
+        rel_std = torch.sqrt((xs / (multiplier * yv)) ** 2 + ((ys * xv) / (multiplier * yv ** 2)) ** 2)
+        return cls(abs_diff, abs_std), cls(rel_diff, rel_std)
+
+    @staticmethod
+    def interpolate(x0: "HipMeasurand", x1: "HipMeasurand", y0: float, y1: float, y: float):
+        """modules/measurand.py:657-681 (std formula as written)."""
+        cls = x0.__class__
+        res = (x0._f64() * (y1 - y) + x1._f64() * (y - y0)) / (y1 - y0)
+        if x0.std is None and x1.std is None:
+            return cls(res, None)
+        a = 0 if x0.std is None else x0.std
+        b = 0 if x1.std is None else x1.std
+        return cls(res, torch.sqrt(a * ((y1 - y) / (y1 - y0)) ** 2 + b * ((y - y0) / (y1 - y0)) ** 2))
+
+
+def _keep(values: torch.Tensor, axis):
+    axes = (axis,) if isinstance(axis, int) else tuple(axis)
+    axes = tuple(a % values.dim() for a in axes)
+    return tuple(1 if d in axes else values.shape[d] for d in range(values.dim()))

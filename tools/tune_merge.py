@@ -58,7 +58,7 @@ def main():
     if a.variants:
         variants = [int(v) for v in a.variants.split(",")]
     else:
-        variants = [0] + [1000 * tab + 100 * pf + 10 * u + bc for tab in (0, 1, 2, 3, 4, 5) for pf in (0, 1)
+        variants = [0] + [1000 * tab + 100 * pf + 10 * u + bc for tab in (0, 1, 2, 4, 5) for pf in (0, 1)
                           for u in (1, 2, 4) for bc in (0, 1)]
     rows = []
     for v in variants:
