@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py - HDR-merged Mpix/s and fraction of the HBM roofline on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A step = one fused merge launch over one synthetic exposure stack that is already resident in HBM.
+Workload (BASELINE.json configs[1], the one the metric is quoted on): 7 x 4096 x 4096 x 3 uint8 frames
++ 256-entry ICRF, val-only merge -> float64 radiance. At N > 1 every rank merges its own stack of the
+same size (independent units, no data-path collective; "weak" scaling); value = all ranks' pixels /
+max-over-ranks time. The roofline block prices the dominant kernel (merge_u8_fast) from its average
+launch duration measured with HIP events on the launch stream inside the timed region; the cpu_baseline
+block times the NumPy oracle (a port of the reference's merge arithmetic) on a bounded row band of the
+same stack on the host, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (frames, H, W, with_std, corrections)
+    "cfg2": (7, 4096, 4096, False, False),      # BASELINE.json configs[1] - the headline
+    "cfg3": (7, 4096, 4096, True, True),        # configs[2]: + float64 std, dark hot-pixel maps, flat field
+    "cfg4tile": (15, 1024, 8192, False, False),  # configs[3]: one of 8 row tiles of 15 x 8192 x 8192 x 3
+}
+
+
+def cpu_baseline(frames, t, icrf, diff, stds, band_rows):
+    """NumPy oracle on rows [0, band_rows) of the bench stack, single thread (NumPy elementwise ops do not
+    multi-thread). kind = "port": the oracle restates the reference's arithmetic (oracle/hdr_oracle.py)."""
+    from oracle import hdr_oracle as orc
+    fh = [f[:band_rows].cpu().numpy() for f in frames]
+    sh = None if stds is None else [s[:band_rows].cpu().numpy() for s in stds]
+    t0 = time.perf_counter()
+    out = orc.merge(fh, t, icrf, diff, stds=sh)
+    dt = time.perf_counter() - t0
+    return out, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the stack the CPU baseline merges")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from camera_linearity_amd import engine
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
+
+    n, H, W, with_std, corr = WORKLOADS[a.workload]
+    frames, stds, t = synthetic_stack_device(7 + rank, n, H, W, device=dev, with_std=with_std)
+    icrf, diff = synthetic_icrf()
+    kw = {}
+    if corr:
+        flat, flat_std, dark = synthetic_flat_dark(7 + rank, H, W, device=dev)
+        x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
+        kw.update(flat=flat, flat_std=flat_std, ff_mean=engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy(),
+                  ff_std_mean=engine.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy(),
+                  darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, 0.05)] * n, median_k=3)
+    plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds, variant=a.variant, **kw)
+    alg_bytes = plan.algorithmic_bytes
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        plan.launch()
+    # per-launch HIP events on the launch stream (torch's current stream is the one hm_merge is given)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record()
+        plan.launch()
+        e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in ev]
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # parity spot check of the timed configuration against the oracle on a row band (not timed)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not corr:
+        rows = min(a.cpu_rows, H)
+        ref, dt = cpu_baseline(frames, t, icrf, diff, stds, rows)
+        got = plan.outputs["val"][:rows].cpu().numpy()
+        np.testing.assert_allclose(got, ref["val"], rtol=1e-12)
+        cpu = {"value": round(rows * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+               "sample": f"rows 0..{rows - 1} of the bench stack ({n}x{rows}x{W}x3, {dt:.1f} s), NumPy oracle, 1 thread of "
+                         f"{os.cpu_count()} host cores; output checked against the GPU result (rtol 1e-12)"}
+
+    if rank == 0:
+        avg_us = float(np.mean(kernel_us))
+        achieved = alg_bytes / avg_us / 1e3          # GB/s
+        traffic = None
+        tp = ROOT / "profiles" / "r01_pmc_traffic.json"
+        if tp.exists() and a.workload == "cfg2":
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        mpix = world * a.steps * H * W / elapsed / 1e6
+        line = {
+            "metric": "HDR-merged Mpix/s (node)", "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n}x{H}x{W}x3 uint8 exposure stack per GPU, 256-entry ICRF LUT, "
+                                   + ("float64 std + dark hot-pixel maps + flat field" if corr else
+                                      ("float64 std propagation" if with_std else "val-only merge"))
+                                   + " -> float64 radiance" + (" + uncertainty" if with_std else ""),
+                       "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3,
+                       "parallelism": f"independent stacks x{world}, no collective", "variant": a.variant},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "merge_u8_fast", "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": round(avg_us, 2), "min_launch_us": round(float(np.min(kernel_us)), 2)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

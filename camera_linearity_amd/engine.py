@@ -244,13 +244,20 @@ class MergePlan:
     def __init__(self, args: nat.MergeArgs, keep: list, device, outputs: dict):
         self.args = args
         self._keep = keep
-        self.device = device
+        self.device = torch.device(device)
         self.outputs = outputs
+        self._ref = C.byref(args)
 
     def launch(self, stream: Optional[int] = None) -> None:
-        with torch.cuda.device(self.device):
-            rc = nat.lib.hm_merge(C.byref(self.args), _stream(self.device) if stream is None else stream)
-        nat.check(rc, "hm_merge")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        if torch.cuda.current_device() == self.device.index:
+            rc = nat.lib.hm_merge(self._ref, stream)
+        else:
+            with torch.cuda.device(self.device):
+                rc = nat.lib.hm_merge(self._ref, stream)
+        if rc:
+            nat.check(rc, "hm_merge")
 
     @property
     def algorithmic_bytes(self) -> int:

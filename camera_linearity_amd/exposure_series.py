@@ -1,0 +1,302 @@
+"""ExposureSeries / ExposurePair - mirror of modules/exposure_series.py:18-495 on the HIP backend.
+
+The reference's merge is two Python loops over the frames (exposure_series.py:334-341 and :372-392),
+each iteration a couple of dozen whole-image NumPy temporaries plus disk reads. Here
+`process_HDR_image` hands the whole stack to ONE fused HIP launch (engine.plan_merge -> hm_merge):
+sum of weights, linearization, weighted radiance, variance propagation, hot-pixel filtering and the
+flat-field step happen per pixel in registers, every input byte is read once.
+
+Deviations: C/D - accumulators are plain zero-initialised arrays and S, S**2 are arrays;
+E - the caller passes ICRF (and optionally ICRF_diff, else it is derived with the reference's
+gradient convention); G - the corrections are applied; J - frames are taken from memory (they are
+loaded from `path` only when an ImageSet holds no pixels yet).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import settings as gs
+from .image_set import ImageSet
+from .measurand import HipMeasurand
+
+
+def icrf_derivative(ICRF, bits: int = None):
+    """ICRF_diff[:, c] = np.gradient(ICRF[:, c], 2 / (BITS - 1)) - the convention of
+    modules/general_functions.py:268-272 and tests/unit/test_measurand.py:21 (host, 256 x C numbers)."""
+    bits = gs.BITS if bits is None else bits
+    icrf = ICRF.cpu().numpy() if isinstance(ICRF, torch.Tensor) else np.asarray(ICRF, dtype=np.float64)
+    dx = 2 / (bits - 1)
+    if icrf.ndim == 1:
+        return np.gradient(icrf, dx)
+    out = np.zeros_like(icrf)
+    for c in range(icrf.shape[1]):
+        out[:, c] = np.gradient(icrf[:, c], dx)
+    return out
+
+
+def read_ICRF_file(file_path, return_derivative: bool = True):
+    """modules/general_functions.py:254-277 with the intended return value (the derivative, not the ICRF twice)."""
+    icrf = np.loadtxt(file_path, dtype=float)
+    return (icrf, icrf_derivative(icrf)) if return_derivative else (icrf, None)
+
+
+class ExposurePair(object):
+    """modules/exposure_series.py:18-76."""
+
+    def __init__(self, short_exposure: ImageSet, long_exposure: ImageSet):
+        self.short_exposure = short_exposure
+        self.long_exposure = long_exposure
+        self.exposure_ratio = short_exposure.features["exposure"] / long_exposure.features["exposure"]
+        self.absolute_difference = None
+        self.relative_difference = None
+        self.absolute_stats = None
+        self.relative_stats = None
+
+    def compute_difference(self):
+        self.absolute_difference, self.relative_difference = ImageSet.compute_difference(self.short_exposure, self.long_exposure)
+
+    def compute_stats(self, axis=None, release_memory_after: Optional[bool] = True):
+        self.absolute_stats = self.absolute_difference.measurand.compute_dimension_statistics(axis=axis)
+        self.relative_stats = self.relative_difference.measurand.compute_dimension_statistics(axis=axis)
+        if release_memory_after:
+            self.absolute_difference = None
+            self.relative_difference = None
+
+    def process_linearity_distribution(self, bins: int, included_range=None, channels=None, use_std: Optional[bool] = False):
+        return (self.absolute_difference.measurand.compute_channel_histogram(bins, included_range, channels, use_std),
+                self.relative_difference.measurand.compute_channel_histogram(bins, included_range, channels, use_std))
+
+
+class ExposureSeries(object):
+    """modules/exposure_series.py:79-476."""
+
+    def __init__(self, merged_image_set: Optional[ImageSet] = None, directory_path: Optional[Path] = None,
+                 input_image_sets: Optional[List[ImageSet]] = None, use_cupy: Optional[bool] = True):
+        self.merged_image_set = merged_image_set
+        self.input_image_sets = input_image_sets if input_image_sets is not None else []
+        if isinstance(directory_path, Path) and directory_path.suffix != "":
+            self.directory_path = directory_path.parent
+        else:
+            self.directory_path = directory_path
+        self.exposure_pairs = None
+        self._use_cupy = use_cupy if not input_image_sets else input_image_sets[0].use_cupy
+
+    @property
+    def use_cupy(self):
+        return self._use_cupy
+
+    @use_cupy.setter
+    def use_cupy(self, new_value):
+        raise AttributeError("use_cupy is a read-only attribute, managing the state of the used array backend.")
+
+    # ---- constructors (exposure_series.py:117-203)
+    @classmethod
+    def from_image_set(cls, reference_image_set: ImageSet, directory_path: Optional[Path] = None):
+        search_path = reference_image_set.path.parent if directory_path is None else directory_path
+        found = [s for s in ImageSet.multiple_from_path(search_path) if reference_image_set.is_exposure_match(s)]
+        found.sort(key=lambda s: s.features["exposure"])
+        return cls(directory_path=search_path, input_image_sets=found)
+
+    @classmethod
+    def from_dir_path(cls, directory_path: Path):
+        return cls.from_multiple_image_sets(ImageSet.multiple_from_path(directory_path))
+
+    @classmethod
+    def from_multiple_image_sets(cls, list_of_image_sets: List[ImageSet]):
+        sublists: List[List[ImageSet]] = []
+        for image_set in list_of_image_sets:
+            for sub in sublists:
+                if sub[0].is_exposure_match(image_set):
+                    sub.append(image_set)
+                    break
+            else:
+                sublists.append([image_set])
+        out = []
+        for sub in sublists:
+            sub.sort(key=lambda s: s.features["exposure"])
+            out.append(cls(input_image_sets=sub))
+        return out
+
+    def load_value_images(self, bit_64: Optional[bool] = False):
+        for image_set in self.input_image_sets:
+            image_set.load_value_image(bit64=bit_64)
+
+    def load_std_images(self, bit_64: Optional[bool] = False):
+        for image_set in self.input_image_sets:
+            image_set.load_std_image(bit64=bit_64)
+
+    def linearize(self, ICRF, ICRF_diff=None, release_memory: Optional[bool] = False):
+        """exposure_series.py:226-250."""
+        new_sets = []
+        for s in self.input_image_sets or []:
+            new_sets.append(s.linearize(ICRF, ICRF_diff))
+            if release_memory:
+                s.measurand.val = None
+                s.measurand.std = None
+        return ExposureSeries(merged_image_set=self.merged_image_set, directory_path=self.directory_path, input_image_sets=new_sets)
+
+    def extract(self, channels=None, release_memory: Optional[bool] = False):
+        new_merged = self.merged_image_set.extract(channels) if self.merged_image_set is not None else None
+        new_sets = []
+        for s in self.input_image_sets or []:
+            new_sets.append(s.extract(channels))
+            if release_memory:
+                s.measurand.val = None
+                s.measurand.std = None
+        return ExposureSeries(merged_image_set=new_merged, directory_path=self.directory_path, input_image_sets=new_sets)
+
+    def initialize_exposure_pairs(self):
+        """exposure_series.py:283-304."""
+        pairs = []
+        for i, x in enumerate(self.input_image_sets):
+            for j, y in enumerate(self.input_image_sets):
+                if i >= j or x.features["exposure"] / y.features["exposure"] < 0.1:
+                    continue
+                pairs.append(ExposurePair(x, y))
+        self.exposure_pairs = pairs
+
+    # ---- the merge (exposure_series.py:317-419)
+    def _stack_inputs(self, list_of_dark_fields, dark_threshold, with_std):
+        """Collect device tensors for the fused launch: frames (all uint8 DNs or all float64 values),
+        stds, per-frame dark DN maps + DN thresholds."""
+        from . import engine
+        sets = self.input_image_sets
+        for s in sets:
+            if s.measurand.shape is None:
+                s.load_value_image()
+        all_dn = all(s.measurand.dn is not None for s in sets)
+        frames = [s.measurand.dn if all_dn else s.measurand._f64() for s in sets]
+        stds = None
+        if with_std:
+            for s in sets:
+                if s.measurand.std is None:
+                    s.load_std_image()
+                if s.measurand.std is None:
+                    raise ValueError("uncertainty propagation needs a std image for every frame")
+            stds = [s.measurand.std for s in sets]
+        thr = gs.DARK_THRESHOLD if dark_threshold is None else dark_threshold
+        darks, mins = None, None
+        if list_of_dark_fields:
+            darks, mins = [], []
+            for s in sets:
+                dark, scale = s.select_dark_field(list_of_dark_fields, thr)
+                if dark is None:
+                    darks.append(None)
+                    mins.append(gs.BITS)
+                    continue
+                if dark.measurand.shape is None:
+                    dark.load_value_image()
+                if dark.measurand.dn is not None:
+                    darks.append(dark.measurand.dn)
+                    mins.append(engine.dark_min_dn(scale, thr))
+                else:                                   # float-valued dark: 0/1 map, hot iff value*scale > thr
+                    darks.append(((dark.measurand.val * scale) > thr).to(torch.uint8))
+                    mins.append(1)
+        return frames, stds, darks, mins
+
+    def _precalculate_sum_of_weights(self, list_of_dark_fields: Optional[List[ImageSet]] = None,
+                                     dark_threshold: Optional[float] = None):
+        """exposure_series.py:317-345 -> (S, S**2) device arrays."""
+        from . import engine
+        frames, _, darks, mins = self._stack_inputs(list_of_dark_fields, dark_threshold, with_std=False)
+        return engine.sum_of_weights(frames, darks=darks, dark_min=mins, median_k=gs.MEDIAN_FILTER_KERNEL_SIZE)
+
+    def _compute_HDR_image_set(self, list_of_dark_fields, sum_of_weights, square_sum_of_weights, ICRF, ICRF_diff,
+                               flat_set: Optional[ImageSet] = None, dark_threshold: Optional[float] = None,
+                               use_std: Optional[bool] = None):
+        """exposure_series.py:347-397. The fused kernel recomputes the sum of weights in registers, so the
+        two precalculated arrays are accepted for signature compatibility and not read."""
+        from . import engine
+        sets = self.input_image_sets
+        if use_std is None:
+            use_std = all(s.measurand.std is not None for s in sets)
+        frames, stds, darks, mins = self._stack_inputs(list_of_dark_fields, dark_threshold, with_std=use_std)
+        if ICRF_diff is None and use_std:
+            ICRF_diff = icrf_derivative(ICRF)
+        kw = {}
+        if flat_set is not None:                                   # exposure_series.py:415-417
+            if flat_set.measurand.shape is None:
+                flat_set.load_value_image()
+            fval = flat_set.measurand.dn if flat_set.measurand.dn is not None else flat_set.measurand._f64()
+            size_x = gs.IM_SIZE_X or fval.shape[0]
+            size_y = gs.IM_SIZE_Y or fval.shape[1]
+            x0, x1, y0, y1 = engine.flat_roi_bounds(size_x, size_y, gs.FF_MID_PERCENTAGE)
+            kw.update(flat=fval, ff_mean=engine.roi_mean(fval, x0, x1, y0, y1).cpu().numpy())
+            if use_std:
+                if flat_set.measurand.std is None:
+                    flat_set.load_std_image()
+                if flat_set.measurand.std is None:
+                    raise ValueError("flat field needs a std image to propagate uncertainty")
+                kw.update(flat_std=flat_set.measurand.std,
+                          ff_std_mean=engine.roi_mean(flat_set.measurand.std, x0, x1, y0, y1).cpu().numpy())
+        exposures = [s.features["exposure"] for s in sets]
+        out = engine.merge(frames, exposures, ICRF, ICRF_diff if use_std else None, stds, darks=darks, dark_min=mins,
+                           median_k=gs.MEDIAN_FILTER_KERNEL_SIZE, **kw)
+        hdr = HipMeasurand(out["val"], out.get("std"))
+        hdr_set = ImageSet(file_path=sets[0].get_file_path_without_exposure(), features=dict(sets[0].features) if sets[0].features else None,
+                           measurand=hdr)
+        hdr_set.is_HDR = True
+        return hdr_set
+
+    def process_HDR_image(self, ICRF=None, ICRF_diff=None, dark_list: Optional[List[ImageSet]] = None,
+                          flat_list: Optional[List[ImageSet]] = None, use_std: Optional[bool] = None):
+        """exposure_series.py:399-419: merge the input images into self.merged_image_set."""
+        if ICRF is None:
+            raise ValueError("process_HDR_image needs the ICRF array (there is no config-file default in this package)")
+        if not self.input_image_sets:
+            raise ValueError("no input images")
+        flat_set = self.input_image_sets[0].get_flat_field(flat_list) if flat_list else None
+        self.merged_image_set = self._compute_HDR_image_set(dark_list, None, None, ICRF, ICRF_diff, flat_set=flat_set,
+                                                            use_std=use_std)
+
+    # ---- linearity statistics (exposure_series.py:421-476; "next" row f-1)
+    def process_linearity(self, ICRF, linearity_limit: Optional[int] = None, use_std: Optional[bool] = False):
+        lower, upper = map_linearity_limits(linearity_limit, linearity_limit, ICRF)
+        for image_set in self.input_image_sets:
+            if image_set.measurand.shape is None:
+                image_set.load_value_image()
+            if image_set.measurand.std is None and use_std:
+                image_set.load_std_image()
+            image_set.measurand.apply_thresholds(lower, upper)
+        for pair in self.exposure_pairs:
+            pair.compute_difference()
+            pair.compute_stats(axis=(0, 1), release_memory_after=True)
+
+    def collect_exposure_pair_stats(self, return_cupy: Optional[bool] = False):
+        rel = {"ratios": [], "means": [], "stds": [], "errors": []}
+        ab = {"ratios": [], "means": [], "stds": [], "errors": []}
+        for p in self.exposure_pairs:
+            for res, st in ((ab, p.absolute_stats), (rel, p.relative_stats)):
+                res["ratios"].append(p.exposure_ratio)
+                res["means"].append(_host(st["mean"]))
+                res["stds"].append(_host(st["std"]))
+                res["errors"].append(_host(st["error"]))
+        return _to_2d_array(ab), _to_2d_array(rel)
+
+
+def _host(x):
+    return None if x is None else (x.cpu().numpy() if isinstance(x, torch.Tensor) else x)
+
+
+def _to_2d_array(dictionary: Dict):
+    return {k: np.array(v) for k, v in dictionary.items()}
+
+
+def map_linearity_limits(lower_limit: Optional[int], upper_limit: Optional[int], ICRF):
+    """modules/general_functions.py:97-131 (host; returns per-channel lists)."""
+    n = gs.NUM_OF_CHS
+    lower = np.array([gs.LOWER_LIN_LIM if lower_limit is None else lower_limit] * n, dtype="float64")
+    upper = np.array([gs.UPPER_LIN_LIM if upper_limit is None else gs.MAX_DN - upper_limit] * n, dtype="float64")
+    if ICRF is None:
+        lower /= gs.MAX_DN
+        upper /= gs.MAX_DN
+    else:
+        icrf = ICRF.cpu().numpy() if isinstance(ICRF, torch.Tensor) else np.asarray(ICRF)
+        for c in range(n):
+            lower[c] = icrf[int(lower[c]), c]
+            upper[c] = icrf[int(upper[c]), c]
+    return list(lower), list(upper)

@@ -1,0 +1,235 @@
+"""GPU tests of the drop-in API (HipMeasurand / ImageSet / ExposureSeries) - modelled on the reference's
+tests/unit/test_measurand.py (real arrays + Hypothesis properties, atol 1e-8 there) and pinned to the
+operator outputs the reference itself produced (tests/golden/operators.npz)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+from oracle import hdr_oracle as orc  # noqa: E402
+
+RT = 1e-13
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from camera_linearity_amd.measurand_factory import Measurand
+    return Measurand
+
+
+def close(t, ref, rtol=RT):
+    np.testing.assert_allclose(t.cpu().numpy(), ref, rtol=rtol, atol=0)
+
+
+def test_operators_match_reference_outputs(M, golden):
+    g = golden("operators")
+    a, b, sa, sb = g["a"], g["b"], g["sa"], g["sb"]
+    combos = {"ss": (sa, sb), "sn": (sa, None), "ns": (None, sb), "nn": (None, None)}
+    ops = {"add": lambda x, y: x + y, "sub": lambda x, y: x - y, "mul": lambda x, y: x * y,
+           "div": lambda x, y: x / y, "pow": lambda x, y: x ** y}
+    for tag, (s1, s2) in combos.items():
+        A, B = M(a, s1), M(b, s2)
+        for name, fn in ops.items():
+            r = fn(A, B)
+            close(r.val, g[f"{name}_{tag}_val"])
+            if tag == "nn":
+                assert r.std is None
+            else:
+                close(r.std, g[f"{name}_{tag}_std"], 1e-12)
+    A = M(a, sa)
+    for name, r in {"neg": -A, "loge": A.log_e(), "log10": A.log_10(), "rmul": 2.5 * A, "adds": A + 1.5,
+                    "subs": A - 0.125, "muls": A * 3.0, "divs": A / 4.0, "pows": A ** 2, "sqrt": A ** (1 / 2)}.items():
+        close(r.val, g[f"{name}_val"])
+        close(r.std, g[f"{name}_std"], 1e-12)
+    An = M(a)
+    close((An ** 2).val, g["pows_n_val"])
+    assert (An * 3.0).std is None
+    w, dw = A.apply_gaussian_weight()
+    close(w, g["gw_w"], 1e-14)
+    close(dw, g["gw_dw"], 1e-14)
+    ex = A.extract([0, 2], axis=-1)
+    close(ex.val, g["extract_val"])
+    close(ex.std, g["extract_std"])
+    B2 = M(g["b2"], g["sb2"])
+    ad, rd = A.compute_difference(A, B2, 0.5)
+    close(ad.val, g["cd_abs_val"]); close(ad.std, g["cd_abs_std"]); close(rd.val, g["cd_rel_val"]); close(rd.std, g["cd_rel_std"])
+    ip = A.interpolate(A, B2, 1.0, 3.0, 1.5)
+    close(ip.val, g["interp_val"]); close(ip.std, g["interp_std"])
+    st_ = M(g["a_nan"].copy(), g["sa_nan"].copy()).compute_dimension_statistics(axis=(0, 1))
+    close(st_["mean"], g["stat_s_mean"], 1e-12); close(st_["std"], g["stat_s_std"], 1e-12); close(st_["error"], g["stat_s_err"], 1e-12)
+    st_ = M(g["a_nan"].copy()).compute_dimension_statistics(axis=(0, 1))
+    close(st_["mean"], g["stat_n_mean"], 1e-12); close(st_["std"], g["stat_n_std"], 1e-12)
+    T = M(a.copy(), sa.copy())
+    T.apply_thresholds([0.4, None, 0.5], [1.0, 0.9, None])
+    np.testing.assert_array_equal(T.val.cpu().numpy(), g["thr_val"])
+    np.testing.assert_array_equal(T.std.cpu().numpy(), g["thr_std"])
+    with pytest.raises(ValueError):
+        T.apply_thresholds([0.1], None)
+    z = A.zeros_like_measurand()
+    assert float(z.val.abs().sum()) == 0.0 and z.std.shape == A.std.shape
+    with pytest.raises(ValueError):
+        M(np.ones((4, 2))) + M(np.ones((3,)))
+    with pytest.raises(TypeError):
+        A + "x"
+
+
+# ---- Hypothesis properties (tests/unit/test_measurand.py:170-378)
+shapes = st.lists(st.integers(1, 6), min_size=1, max_size=4).map(tuple)
+
+
+@st.composite
+def pair(draw):
+    shp = draw(shapes)
+    cut = draw(st.integers(0, len(shp) - 1))
+    shp2 = tuple(1 if draw(st.booleans()) else s for s in shp[cut:])
+    rng = np.random.default_rng(draw(st.integers(0, 2 ** 31)))
+    a = rng.random(shp) + 0.05
+    b = rng.random(shp2) + 0.05
+    sa = 0.1 * a if draw(st.booleans()) else None
+    sb = 0.1 * b if draw(st.booleans()) else None
+    return a, sa, b, sb
+
+
+@settings(max_examples=25, deadline=None)
+@given(pair())
+def test_operator_properties(M, p):
+    a, sa, b, sb = p
+    A, B = M(a, sa), M(b, sb)
+    for name, fn, ofn in (("add", lambda x, y: x + y, orc.op_add), ("sub", lambda x, y: x - y, orc.op_sub),
+                          ("mul", lambda x, y: x * y, orc.op_mul), ("div", lambda x, y: x / y, orc.op_div)):
+        r = fn(A, B)
+        rv, rs = ofn(a, sa, b, sb)
+        close(r.val, rv, 1e-14)
+        if rs is None:
+            assert r.std is None
+        else:
+            close(r.std, rs, 1e-12)
+    # commutativity / identities, atol as in the reference's tests
+    np.testing.assert_allclose((A + B).val.cpu().numpy(), (B + A).val.cpu().numpy(), atol=1e-8)
+    np.testing.assert_allclose((A * B).val.cpu().numpy(), (B * A).val.cpu().numpy(), atol=1e-8)
+    np.testing.assert_allclose((A - A).val.cpu().numpy(), 0, atol=1e-8)
+    np.testing.assert_allclose((A / A).val.cpu().numpy(), 1, atol=1e-8)
+    np.testing.assert_allclose(((A * B) / B).val.cpu().numpy(), np.broadcast_to(a, np.broadcast_shapes(a.shape, b.shape)), atol=1e-8)
+
+
+@settings(max_examples=15, deadline=None)
+@given(st.integers(1, 4), st.integers(1, 9), st.integers(1, 9), st.integers(0, 2 ** 31), st.booleans())
+def test_linearize_property(M, c, h, w, seed, with_std):
+    """tests/unit/test_measurand.py:447-467: every output is a member of its channel's ICRF column - and,
+    beyond the reference's test, it is exactly ICRF[idx, c] with the shape preserved."""
+    rng = np.random.default_rng(seed)
+    v = rng.random((h, w, c))
+    s = 0.1 * v if with_std else None
+    icrf = np.stack([np.linspace(0, 1, 256) ** (k + 1) for k in range(c)], axis=1)
+    diff = np.stack([np.gradient(icrf[:, k], 2 / 255) for k in range(c)], axis=1)
+    r = M(v, s).linearize(icrf, diff)
+    assert tuple(r.val.shape) == (h, w, c)
+    rv, rs, idx = orc.linearize(v, s, icrf, diff)
+    assert np.array_equal(r.val.cpu().numpy(), rv)
+    for k in range(c):
+        assert np.isin(r.val[..., k].cpu().numpy(), icrf[:, k]).all()
+    if with_std:
+        close(r.std, rs, 1e-15)
+    else:
+        assert r.std is None
+    assert np.array_equal(M(v).lut_index().cpu().numpy(), idx)
+
+
+def _features(t):
+    return {"illumination": "bf", "magnification": "5x", "exposure": float(t), "subject": "s"}
+
+
+def test_exposure_series_process_hdr_image(golden):
+    """The full drop-in path: ImageSets in memory -> ExposureSeries.process_HDR_image -> merged ImageSet,
+    with dark-frame filtering and flat-field correction, against the reference-generated vectors."""
+    from camera_linearity_amd import settings as gs
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    g = golden("merge_full")
+    old = (gs.DARK_THRESHOLD, gs.FF_MID_PERCENTAGE, gs.MEDIAN_FILTER_KERNEL_SIZE)
+    gs.configure(DARK_THRESHOLD=float(g["dark_threshold"]), FF_MID_PERCENTAGE=float(g["ff_mid"]),
+                 MEDIAN_FILTER_KERNEL_SIZE=int(g["median_k"]))
+    try:
+        sets = [ImageSet(value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+        darks = [ImageSet(value=g[k], features=dict(_features(e), subject="dark"))
+                 for k, e in (("dark16", 0.016), ("dark32", 0.032), ("dark64", 0.064))]
+        flat = ImageSet(value=g["flat"], std=g["flat_std"], features=dict(_features(0.01), subject="flat"))
+        series = ExposureSeries(input_image_sets=sets)
+        series.process_HDR_image(g["icrf"], g["icrf_diff"], dark_list=darks, flat_list=[flat])
+        val, std = series.merged_image_set.to_numpy()
+        np.testing.assert_allclose(val, g["val_ff"], rtol=1e-12)
+        np.testing.assert_allclose(std, g["std_ff"], rtol=1e-9)
+        assert series.merged_image_set.is_HDR and series.merged_image_set.measurand.backend == "hip"
+        # ICRF_diff derived with the reference's gradient convention when not given
+        series.process_HDR_image(g["icrf"], dark_list=darks)
+        val, std = series.merged_image_set.to_numpy()
+        np.testing.assert_allclose(val, g["val"], rtol=1e-12)
+        np.testing.assert_allclose(std, g["std"], rtol=1e-9)
+        # val-only (no std images)
+        sets2 = [ImageSet(value=g["frames"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+        s2 = ExposureSeries(input_image_sets=sets2)
+        s2.process_HDR_image(g["icrf"])
+        assert s2.merged_image_set.measurand.std is None
+        np.testing.assert_allclose(s2.merged_image_set.to_numpy()[0], g["val_nohot"], rtol=1e-12)
+        # S and S**2 (exposure_series.py:317-345)
+        S, S2 = ExposureSeries(input_image_sets=sets2)._precalculate_sum_of_weights()
+        ref = orc.merge(list(g["frames"]), g["exposures"], g["icrf"])
+        np.testing.assert_allclose(S.cpu().numpy(), ref["S"], rtol=1e-14)
+        # stack-wide linearize and per-image pass-throughs
+        lin = series.linearize(g["icrf"], g["icrf_diff"])
+        v0, s0, _ = orc.linearize(orc.unit_from_u8(g["frames"][0]), g["stds"][0], g["icrf"], g["icrf_diff"])
+        np.testing.assert_array_equal(lin.input_image_sets[0].to_numpy()[0], v0)
+        filt = sets[6].bad_pixel_filter(darks[2])
+        refv = orc.hot_pixel_filter(orc.unit_from_u8(g["frames"][6]), orc.unit_from_u8(g["dark64"]), float(g["dark_threshold"]), 3)
+        np.testing.assert_array_equal(filt.to_numpy()[0], refv)
+        scaled = darks[2].scale_to_exposure(0.032)
+        assert scaled.features["exposure"] == 0.032 and darks[2].features["exposure"] == 0.064      # deviation I
+        np.testing.assert_allclose(scaled.to_numpy()[0], 0.5 * orc.unit_from_u8(g["dark64"]), rtol=1e-15)
+    finally:
+        gs.configure(DARK_THRESHOLD=old[0], FF_MID_PERCENTAGE=old[1], MEDIAN_FILTER_KERNEL_SIZE=old[2])
+
+
+def test_exposure_series_scaled_dark_selection(golden):
+    from camera_linearity_amd import settings as gs
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    g = golden("merge_dark_scaled")
+    old = gs.DARK_THRESHOLD
+    gs.configure(DARK_THRESHOLD=float(g["dark_threshold"]))
+    try:
+        sets = [ImageSet(value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+        darks = [ImageSet(value=g["darks"][i], features=dict(_features(e), subject="dark")) for i, e in enumerate(g["dark_exposures"])]
+        series = ExposureSeries(input_image_sets=sets)
+        series.process_HDR_image(g["icrf"], g["icrf_diff"], dark_list=darks)
+        val, std = series.merged_image_set.to_numpy()
+        np.testing.assert_allclose(val, g["val"], rtol=1e-12)
+        np.testing.assert_allclose(std, g["std"], rtol=1e-9)
+    finally:
+        gs.configure(DARK_THRESHOLD=old)
+
+
+def test_exposure_pairs_and_linearity_stats():
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    frames, stds, t = orc.synthetic_stack(5, 4, 16, 12, with_std=True)
+    sets = [ImageSet(value=orc.unit_from_u8(f), std=s, features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
+    series = ExposureSeries(input_image_sets=sets)
+    series.initialize_exposure_pairs()
+    assert len(series.exposure_pairs) == 6
+    icrf, _ = orc.synthetic_icrf((1.0, 1.0, 1.0))
+    series.process_linearity(icrf, linearity_limit=5, use_std=True)
+    ab, rel = series.collect_exposure_pair_stats()
+    assert ab["means"].shape == (6, 3) and rel["stds"].shape == (6, 3)
+    # first pair against the oracle formulas
+    lo, hi = icrf[5, 0], icrf[250, 0]
+    v0, s0 = orc.apply_thresholds(orc.unit_from_u8(frames[0]), stds[0], [lo] * 3, [hi] * 3)
+    v1, s1 = orc.apply_thresholds(orc.unit_from_u8(frames[1]), stds[1], [lo] * 3, [hi] * 3)
+    ad, ads, rd, rds = orc.compute_difference(v0, s0, v1, s1, t[0] / t[1])
+    ref = orc.dimension_statistics(ad, ads, (0, 1))
+    np.testing.assert_allclose(ab["means"][0], ref["mean"], rtol=1e-10)
+    np.testing.assert_allclose(ab["stds"][0], ref["std"], rtol=1e-10)

@@ -1,0 +1,182 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/hdrmerge.h declares, argument
+validation that needs no device, host-side logic (settings, file-name grammar, dark selection, ROI bounds,
+row tiles, weight tables) and constructor/type errors modelled on the reference's
+tests/unit/test_measurand.py:120-167 and tests/unit/test_image_set.py:317-361."""
+import ctypes as C
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+from oracle import hdr_oracle as orc
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from camera_linearity_amd import _native as nat
+    header = (ROOT / "include" / "hdrmerge.h").read_text()
+    declared = set(re.findall(r"\b(hm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"hm_merge_args"}
+    assert declared == set(nat.EXPORTED_SYMBOLS), declared ^ set(nat.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(nat.lib, name)
+    assert nat.lib.hm_version() == 1
+    assert nat.strerror(0) == "ok" and "geometry" in nat.strerror(nat.HM_ESHAPE)
+    assert "unknown" in nat.strerror(-99)
+
+
+def test_merge_args_layout_matches_header():
+    from camera_linearity_amd import _native as nat
+    # offsets of include/hdrmerge.h's struct on LP64 (checked against a C compile in the build container)
+    assert C.sizeof(nat.MergeArgs) == 264
+    assert nat.MergeArgs.frames_u8.offset == 64 and nat.MergeArgs.ff_mean.offset == 176
+    assert nat.MergeArgs.out_sum_w.offset == 256
+
+
+def test_argument_validation_without_device():
+    """Validation happens before any HIP call, so it can be exercised on a box without a GPU."""
+    from camera_linearity_amd import _native as nat
+    assert nat.lib.hm_merge(None, None) == nat.HM_EINVAL
+    a = nat.MergeArgs()
+    a.struct_size = 1
+    assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EINVAL            # wrong struct size
+    a.struct_size = C.sizeof(nat.MergeArgs)
+    a.n_frames, a.channels, a.height, a.width, a.rows, a.buf_rows = 40, 3, 4, 4, 4, 4
+    assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EUNSUPPORTED      # > HM_MAX_FRAMES
+    a.n_frames = 2
+    assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EINVAL            # no frames given
+    assert nat.lib.hm_merge_algorithmic_bytes(C.byref(a)) == 2 * 48       # 2 uint8 frames, no outputs requested
+    assert nat.lib.hm_linearize_u8(None, None, None, None, None, None, 0, 3, 3, None) == nat.HM_EINVAL
+    assert nat.lib.hm_binary_op(9, None, None, None, None, None, None, 1, None, None, None, None) == nat.HM_EINVAL
+    assert nat.lib.hm_roi_mean_workspace_bytes() >= 8 * 4
+    with pytest.raises(ValueError):
+        nat.check(nat.HM_ESHAPE)
+    with pytest.raises(NotImplementedError):
+        nat.check(nat.HM_EUNSUPPORTED)
+    with pytest.raises(nat.HdrMergeError):
+        nat.check(nat.HM_ELAUNCH)
+
+
+def test_host_weight_lut_helper_close_to_numpy():
+    from camera_linearity_amd import _native as nat
+    w = (C.c_double * 256)()
+    dw = (C.c_double * 256)()
+    assert nat.lib.hm_gaussian_weight_lut_host(w, dw) == 0
+    rw, rdw = orc.gaussian_weight_lut()
+    np.testing.assert_allclose(np.array(w), rw, rtol=4e-16)
+    np.testing.assert_allclose(np.array(dw), rdw, rtol=4e-16)
+
+
+def test_engine_weight_tables_bit_identical_to_reference_values(golden):
+    from camera_linearity_amd import engine
+    w, dw = engine.weight_luts_host()
+    g = golden("merge_ramp")
+    assert np.array_equal(w, g["w_lut"]) or np.allclose(w, g["w_lut"], rtol=2e-16, atol=0)
+    np.testing.assert_allclose(dw, g["dw_lut"], rtol=2e-16)
+
+
+def test_dark_min_dn_equivalent_to_value_threshold():
+    from camera_linearity_amd import engine
+    for scale, thr in ((1.0, 0.05), (0.4, 0.03), (0.8, 0.012), (1.0, 2.0), (1.0, -1.0)):
+        v = orc.unit_from_u8(np.arange(256, dtype=np.uint8))
+        v = v if scale == 1.0 else np.array([scale]) * v
+        hot = v > thr
+        m = engine.dark_min_dn(scale, thr)
+        assert np.array_equal(np.arange(256) >= m, hot)
+
+
+def test_roi_bounds_and_row_tiles():
+    from camera_linearity_amd import engine, parallel
+    assert engine.flat_roi_bounds(32, 48, 0.2) == orc.flat_roi_bounds(32, 48, 0.2) == (12, 18, 18, 27)
+    for H in (0, 1, 7, 4096, 8191):
+        for G in (1, 2, 3, 8):
+            b = parallel.row_tile_bounds(H, G)
+            assert b[0][0] == 0 and b[-1][1] == H and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            assert max(r1 - r0 for r0, r1 in b) - min(r1 - r0 for r0, r1 in b) <= 1
+    assert parallel.halo_bounds(0, 10, 40, 3) == (0, 11) and parallel.halo_bounds(10, 40, 40, 5) == (8, 40)
+    assert parallel.halo_bounds(10, 20, 40, 0) == (10, 20)
+    assert parallel.stacks_for_rank(10, 1, 4) == [1, 5, 9]
+
+
+def test_file_name_features():
+    """The table of the reference's tests/unit/test_image_set.py:317-327."""
+    from camera_linearity_amd.image_set import _features_from_file_name
+    P = pathlib.Path
+    assert _features_from_file_name(P("5ms BF sample_1 50x.tif")) == {
+        "illumination": "BF", "magnification": "50x", "exposure": 0.005, "subject": "sample_1"}
+    f = _features_from_file_name(P("/data/x/df 0.5ms 10X rock.tif"))
+    assert f == {"illumination": "df", "magnification": "10X", "exposure": 0.0005, "subject": "rock"}
+    assert _features_from_file_name(P("flat.tif")) == {"illumination": "", "magnification": "", "exposure": 0.0, "subject": "flat"}
+
+
+def test_measurand_constructor_errors_and_properties():
+    """modules/measurand.py:55-56,68-69,84,698-710 / tests/unit/test_measurand.py:120-167."""
+    import torch
+    from camera_linearity_amd.measurand import HipMeasurand, is_broadcastable
+    from camera_linearity_amd.measurand_factory import Measurand
+    with pytest.raises(TypeError):
+        HipMeasurand("invalid")
+    with pytest.raises(TypeError):
+        HipMeasurand(np.ones(3), "invalid")
+    with pytest.raises(ValueError):
+        HipMeasurand(torch.ones(3, dtype=torch.float64), torch.ones(4, dtype=torch.float64))
+    m = HipMeasurand(2.0, 0.5)
+    assert tuple(m.val.shape) == (1,) and m.val.dtype == torch.float64 and float(m.std[0]) == 0.5
+    with pytest.raises(AttributeError):
+        m.channels = None
+    with pytest.raises(TypeError):
+        m.val = [1, 2, 3]
+    with pytest.raises(TypeError):
+        m.std = "x"
+    m.val = np.zeros((4, 5, 3))
+    assert list(m.channels.cpu().numpy()) == [0, 1, 2]                   # deviation B: arange(shape[-1])
+    assert HipMeasurand(torch.zeros((2, 2, 4), dtype=torch.float64)).channels.numel() == 4
+    with pytest.raises(NotImplementedError):
+        Measurand(np.zeros(3), use_cupy=False)
+    assert Measurand().val is None and Measurand().backend == "hip"
+    assert is_broadcastable((4, 1, 3), (5, 3)) and not is_broadcastable((4, 2), (3,))
+    with pytest.raises(ValueError):
+        is_broadcastable((), (1,))
+    with pytest.raises(TypeError):
+        m._normalize_input("abc")
+
+
+def test_image_set_backend_checks_and_dark_selection():
+    from camera_linearity_amd.image_set import ImageSet
+    from camera_linearity_amd.measurand import HipMeasurand
+
+    class Fake:
+        backend = "numpy"
+    with pytest.raises(ValueError):
+        ImageSet(measurand=Fake())
+    s = ImageSet(value=np.zeros((2, 2, 3), np.uint8), features={"exposure": 0.04, "illumination": "bf", "magnification": "5x", "subject": "a"})
+    with pytest.raises(AttributeError):
+        s.use_cupy = False
+    with pytest.raises(ValueError):
+        s.measurand = Fake()
+    assert s.measurand.dn is not None and s.measurand.dn.dtype.is_floating_point is False
+    mk = lambda e: ImageSet(features={"exposure": e, "illumination": "bf", "magnification": "5x", "subject": "dark"},   # noqa: E731
+                            measurand=HipMeasurand())
+    darks = [mk(0.010), mk(0.050), mk(0.100)]
+    for t_exp in (0.020, 0.040, 0.050, 0.080, 0.2, 0.005):
+        s.features["exposure"] = t_exp
+        d, sc = s.select_dark_field(darks, 0.03)
+        j, osc = orc.select_dark(t_exp, [0.010, 0.050, 0.100], 0.03)
+        assert (d is None and j < 0) or d is darks[j]
+        assert sc == pytest.approx(osc, rel=1e-15)
+    other = ImageSet(features=dict(s.features, exposure=1.0), measurand=HipMeasurand())
+    assert s.is_exposure_match(other) and not s.is_exposure_match(mk(1.0))
+
+
+def test_settings_configure():
+    from camera_linearity_amd import settings
+    old = settings.DARK_THRESHOLD
+    settings.configure(DARK_THRESHOLD=0.012)
+    assert settings.DARK_THRESHOLD == 0.012
+    settings.configure(DARK_THRESHOLD=old)
+    with pytest.raises(KeyError):
+        settings.configure(NOPE=1)
+    with pytest.raises(NotImplementedError):
+        settings.configure(BITS=1024)
