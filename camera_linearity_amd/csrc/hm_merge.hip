@@ -13,7 +13,7 @@
 // the first ceiling, so the val-only kernel replicates the tables across LDS banks (TAB_* below).
 //
 // Two kernels:
-//   merge_u8_fast   C == 3, N <= 16 (compile-time), 4-byte-aligned uint8 frames; the bench path.
+//   merge_u8_fast   C == 3, N <= 16 (compile-time), 2-byte-aligned uint8 frames; the bench path.
 //   merge_generic   anything else (float64 frames, other C, N <= 32, tails, unaligned tiles):
 //                   one element per thread, same arithmetic.
 #include "hm_common.h"
@@ -237,32 +237,12 @@ constexpr int kStdTabBytes = 16 * 256 + 16 * 768;
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p));
 }
 __device__ __forceinline__ void store2(double* p, double x, double y) {
     f64x2 v; v.x = x; v.y = y;
     __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(p));
-}
-
-// Coalesced output: lane l of a sub-unit holds elements 4l..4l+3 (32 contiguous output bytes), which as
-// a direct store is a 32-byte-stride pattern - measured 149 us vs 125 us for the same traffic with
-// fully contiguous 1 KB store instructions (tools/membench.hip). So the 4 values go through a
-// wave-private 2 KB LDS slab: written as [lane][4], read back as [k][lane][2], then two
-// global_store_dwordx4 that each cover 1 KB. DS operations of one wave execute in issue order, so no
-// barrier is needed; the wave_barrier only pins the compiler's ordering.
-__device__ __forceinline__ void store4_coalesced(char* slab, uint32_t lane, double* out_sub,
-                                                 double v0, double v1, double v2, double v3) {
-    f64x2 a, b;
-    a.x = v0; a.y = v1; b.x = v2; b.y = v3;
-    *reinterpret_cast<f64x2*>(slab + lane * 32u) = a;
-    *reinterpret_cast<f64x2*>(slab + lane * 32u + 16u) = b;
-    __builtin_amdgcn_wave_barrier();
-    const f64x2 lo = *reinterpret_cast<const f64x2*>(slab + lane * 16u);
-    const f64x2 hi = *reinterpret_cast<const f64x2*>(slab + 1024u + lane * 16u);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_nontemporal_store(lo, reinterpret_cast<f64x2*>(out_sub + 2u * lane));
-    __builtin_nontemporal_store(hi, reinterpret_cast<f64x2*>(out_sub + 128u + 2u * lane));
 }
 
 // fill the val-only tables; blockDim-agnostic
@@ -341,28 +321,35 @@ __device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_
     }
 }
 
-// Work decomposition of the fast kernel: a wave owns "groups" of U * 256 consecutive elements. Inside
-// a group, sub-unit s (0..U-1) is a 256-element segment and lane l handles its elements 4l .. 4l+3:
-// one coalesced global_load_dword per (frame, sub-unit) (256 contiguous bytes per wave instruction,
-// immediate offsets 256*s off one scalar base address) and 32 contiguous output bytes per lane per
-// sub-unit. All group-level address arithmetic is scalar (the group index is wave-uniform).
-// All N*U loads of a group are issued before the first gather; with PREFETCH the loads of the wave's
-// NEXT group are issued before the current group is processed (a 1-block-per-CU launch has only 4
-// waves per SIMD, so memory-level parallelism has to come from the instruction stream).
-// Channel of element 256*s + 4*l + j of group g: (g*U*256 + 256*s + 4*l + j) % 3 = (g*U + s + l + j) % 3.
+// Work decomposition of the fast kernel (tools/membench2.hip and tools/mergelab.hip are the experiments
+// behind it): a wave owns "groups" of U * 128 consecutive elements. In a 128-element sub-unit lane l
+// handles elements 2l and 2l+1:
+//   * input: one global_load_ushort per (frame, sub-unit), 128 contiguous bytes per wave instruction,
+//     immediate offsets 128*s off one scalar base; with U = 4 a wave streams 512 contiguous bytes per
+//     frame, the span that measured best for this 7-in / 1-out traffic shape;
+//   * output: lane l owns the 16 contiguous bytes of elements 2l, 2l+1, so every store instruction is
+//     one fully contiguous 1 KB global_store_dwordx4 (nontemporal) - no cross-lane transposition.
+//     (Store instructions must cover whole 128-byte lines: 4 elements per lane stored directly is a
+//     32-byte-stride pattern that costs 146 us instead of 128 us for the traffic alone; transposing
+//     through LDS fixed that but added 13 % to an LDS pipe that bank conflicts already fill.)
+// All group-level address arithmetic is scalar (the group index is wave-uniform). All N*U loads of a
+// group are issued before the first gather; PREFETCH issues the next group's loads first.
+// Channel of element 2l + j of sub-unit s of group g: (g*U*128 + 128*s + 2l + j) % 3 = (2*(g*U + s + l) + j) % 3.
 //
 // EXTRAS = flat-field epilogue and/or sum-of-weights output compiled in (runtime-selected inside);
 // the plain instantiation has a branch-free epilogue.
 
-// keeps an accumulator chain where the source puts it (hipcc otherwise sinks the chains of elements
-// 1..3 below the first element's epilogue and keeps every gathered value live until then)
+// keeps an accumulator chain where the source puts it (hipcc otherwise sinks the second element's chain
+// below the first element's epilogue and keeps every gathered value live until then)
 #define HM_PIN(x) asm volatile("" : "+v"(x))
+
+constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 
 template <int NF, int U, int TAB, bool STD, bool HOT, bool PREFETCH, bool EXTRAS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int C = 3;
-    constexpr uint32_t GROUP = U * 256;
+    constexpr uint32_t GROUP = U * kSub;
     if constexpr (!STD) {
         fill_val_tables<TAB>(lds, a);
     } else {
@@ -374,13 +361,12 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t lane4 = lane * 4u;
+    const uint32_t lane2 = lane * 2u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr uint32_t WPB = BLOCK / 64;
     const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / GROUP);
     const uint32_t gstride = gridDim.x * WPB;
     const uint32_t woff = lane_woff<TAB>();
-    char* slab = lds + (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + wave * 2048u;   // wave-private transpose slab
 
     uint32_t g = blockIdx.x * WPB + wave;                                   // wave-uniform
     uint32_t raw[NF][U];
@@ -390,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
         for (int i = 0; i < NF; ++i) {
             const uint8_t* p = static_cast<const uint8_t*>(a.frame[i]) + off;
 #pragma unroll
-            for (int s = 0; s < U; ++s) dst[i][s] = ld_u32(p + 256 * s + lane4);
+            for (int s = 0; s < U; ++s) dst[i][s] = ld_u16(p + kSub * s + lane2);
         }
     };
     if (PREFETCH && g < n_groups) load_group(g, raw);
@@ -410,10 +396,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
 
 #pragma unroll
         for (int s = 0; s < U; ++s) {
-            const int64_t sbase = gbase + 256 * s;                          // scalar
-            const int64_t e0 = sbase + lane4;
-            const int64_t ei0 = a.in_off + e0; (void)ei0;
-            const uint32_t c0 = (g * U + s + lane) % 3u;
+            const int64_t sbase = gbase + kSub * s;                         // scalar
+            const int64_t e0 = sbase + lane2;
+            const uint32_t c0 = (2u * (g * U + s + lane)) % 3u;
 
             // hot-pixel prologue (rare): replace the DN by the k x k median of its frame
             uint32_t hotmask[NF];
@@ -422,12 +407,11 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 for (int i = 0; i < NF; ++i) {
                     hotmask[i] = 0;
                     if (a.dark[i]) {
-                        const uint32_t dr = ld_u32(a.dark[i] + a.in_off + sbase + lane4);
+                        const uint32_t dr = ld_u16(a.dark[i] + a.in_off + sbase + lane2);
                         const uint32_t thr = static_cast<uint32_t>(a.dark_min[i]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) hotmask[i] |= (((dr >> (8 * j)) & 255u) >= thr) ? (1u << j) : 0u;
+                        hotmask[i] = ((dr & 255u) >= thr ? 1u : 0u) | ((dr >> 8) >= thr ? 2u : 0u);
                         if (hotmask[i]) {
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < 2; ++j) {
                                 if (hotmask[i] & (1u << j)) {
                                     int64_t row, col; int cc; elem_to_pixel(a, e0 + j, row, col, cc);
                                     const uint32_t md = median_at(static_cast<const uint8_t*>(a.frame[i]), a.H, a.W, C,
@@ -440,9 +424,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 }
             }
 
-            uint32_t coffs[3];
+            uint32_t coffs[2];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const uint32_t c = (c0 + k) % 3u;
                 coffs[k] = STD ? c * 16u : lane_coff<TAB>(static_cast<int>(c));
             }
@@ -450,57 +434,57 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
             double* osw = EXTRAS && a.out_sum_w ? a.out_sum_w + sbase : nullptr;
 
             if constexpr (!STD) {
-                double S[4], acc[4];
+                double S[2], acc[2];
 #pragma unroll
                 for (int i = 0; i < NF; ++i) {
                     const double it = a.inv_t[i];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t dn = (cur[i][s] >> (8 * j)) & 255u;
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t dn = j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8);
                         double w, wg;
-                        gather_val<TAB>(lds, dn, woff, coffs[j % 3], w, wg);
+                        gather_val<TAB>(lds, dn, woff, coffs[j], w, wg);
                         if (i == 0) { S[j] = w; acc[j] = wg * it; }
                         else {
                             S[j] += w;                               // exposure_series.py:340
                             acc[j] = fma(wg, it, acc[j]);            // :388 numerator
                         }
                     }
-                    // bound the gathers in flight: at most 2 frames (16 ds_reads, 32 VGPRs) per bundle
-                    if ((i & 1) == 1 || i == NF - 1) {
+                    // bound the gathers in flight (4 frames = 8 ds_reads, 32 VGPRs) per scheduling bundle
+                    if ((i & 3) == 3 || i == NF - 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { HM_PIN(S[j]); HM_PIN(acc[j]); }
+                        for (int j = 0; j < 2; ++j) { HM_PIN(S[j]); HM_PIN(acc[j]); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                double val[4];
+                double val[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) val[j] = acc[j] / S[j];
+                for (int j = 0; j < 2; ++j) val[j] = acc[j] / S[j];
                 if constexpr (EXTRAS) {
                     if (a.has_flat) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < 2; ++j) {
                             double dummy = 0.0;
                             flat_field_apply(a, e0 + j, static_cast<int>((c0 + j) % 3u), false, val[j], dummy);
                         }
                     }
-                    if (osw) store4_coalesced(slab, lane, osw, S[0], S[1], S[2], S[3]);
+                    if (osw) store2(osw + lane2, S[0], S[1]);
                 }
-                store4_coalesced(slab, lane, ov, val[0], val[1], val[2], val[3]);
+                store2(ov + lane2, val[0], val[1]);
             } else {
                 const double2* t_wdw = reinterpret_cast<const double2*>(lds);
                 const char* t_gd = lds + 16 * 256;
                 // pass 1: S = sum_i w_i
-                double S[4];
+                double S[2];
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const double w = t_wdw[(cur[i][s] >> (8 * j)) & 255u].x;
+                    for (int j = 0; j < 2; ++j) {
+                        const double w = t_wdw[j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8)].x;
                         if (i == 0) S[j] = w; else S[j] += w;
                     }
-                double invS[4], invS2[4], acc[4], var[4];
+                double invS[2], invS2[2], acc[2], var[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 2; ++j) {
                     invS[j] = 1.0 / S[j];
                     invS2[j] = 1.0 / (S[j] * S[j]);                  // 1 / S**2, exposure_series.py:343
                     HM_PIN(invS[j]); HM_PIN(invS2[j]);
@@ -511,15 +495,14 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 for (int i = 0; i < NF; ++i) {
                     const double it = a.inv_t[i];
                     const double* sp = a.sd[i] + a.in_off + sbase;                               // scalar base
-                    double sdv[4];
+                    double sdv[2];
                     {
-                        const f64x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sp + lane4));
-                        const f64x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sp + lane4 + 2));
-                        sdv[0] = v0.x; sdv[1] = v0.y; sdv[2] = v1.x; sdv[3] = v1.y;
+                        const f64x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sp + lane2));
+                        sdv[0] = v0.x; sdv[1] = v0.y;
                     }
                     if constexpr (HOT) {
                         if (hotmask[i]) {
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < 2; ++j) {
                                 if (hotmask[i] & (1u << j)) {
                                     int64_t row, col; int cc; elem_to_pixel(a, e0 + j, row, col, cc);
                                     sdv[j] = median_at(a.sd[i], a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
@@ -528,10 +511,10 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t dn = (cur[i][s] >> (8 * j)) & 255u;
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t dn = j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8);
                         const double2 wdw = t_wdw[dn];
-                        const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j % 3]);
+                        const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
                         const double w = wdw.x, dw = wdw.y, gg = gd.x;
                         const double dg = gd.y * sdv[j];                                        // measurand.py:512
                         const double A = (dw * gg + w * dg) * invS[j] - ((dw * w) * gg) * invS2[j];   // :389
@@ -542,26 +525,28 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                             var[j] = fma(term, term, var[j]);
                         }
                     }
+                    if ((i & 1) == 1 || i == NF - 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { HM_PIN(acc[j]); HM_PIN(var[j]); }
-                    __builtin_amdgcn_sched_barrier(0);   // one frame's std loads + gathers at a time
+                        for (int j = 0; j < 2; ++j) { HM_PIN(acc[j]); HM_PIN(var[j]); }
+                        __builtin_amdgcn_sched_barrier(0);   // two frames' std loads + gathers at a time
+                    }
                 }
-                double val[4], so[4];
+                double val[2], so[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 2; ++j) {
                     val[j] = acc[j] / S[j];
                     so[j] = sqrt(var[j]);                                                        // :394
                 }
                 if constexpr (EXTRAS) {
                     if (a.has_flat) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < 2; ++j)
                             flat_field_apply(a, e0 + j, static_cast<int>((c0 + j) % 3u), true, val[j], so[j]);
                     }
-                    if (osw) store4_coalesced(slab, lane, osw, S[0], S[1], S[2], S[3]);
+                    if (osw) store2(osw + lane2, S[0], S[1]);
                 }
-                store4_coalesced(slab, lane, ov, val[0], val[1], val[2], val[3]);
-                store4_coalesced(slab, lane, a.out_std + sbase, so[0], so[1], so[2], so[3]);
+                store2(ov + lane2, val[0], val[1]);
+                store2(a.out_std + sbase + lane2, so[0], so[1]);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep one sub-unit's gathers from piling onto the next one's
         }
@@ -585,26 +570,26 @@ int cu_count() {
 }
 
 // Variant encoding (args->variant; values other than 0 are meaningful in tuning builds only):
-//   variant = 1000 * TAB + 100 * PREFETCH + 10 * U + BLOCK_CODE     BLOCK_CODE: 0 -> 256 threads, 1 -> 1024
+//   variant = 1000 * TAB + 100 * PREFETCH + 10 * U + BLOCK_CODE     U in {2,4,8}; BLOCK_CODE: 0 -> 256 threads, 1 -> 1024
 struct FastCfg { int tab, u, prefetch, block; };
 
 static FastCfg default_cfg(bool with_std) {
-    if (with_std) return FastCfg{TAB_PLAIN, 1, 0, 256};
-    return FastCfg{TAB_FUSED, 2, 0, 256};     // tools/tune_merge.py, profiles/r01_tune_merge.json
+    if (with_std) return FastCfg{TAB_PLAIN, 2, 0, 256};
+    return FastCfg{TAB_FUSED, 2, 0, 256};     // tools/tune_merge.py, tools/mergelab.hip, profiles/
 }
 
 static bool decode_variant(int variant, bool with_std, FastCfg& c) {
     c = default_cfg(with_std);
     if (variant <= 0 || with_std) return true;
     const int tab = variant / 1000, pf = (variant / 100) % 10, u = (variant / 10) % 10, bc = variant % 10;
-    if (tab < 0 || tab > TAB_NONE || pf > 1 || (u != 1 && u != 2 && u != 4) || bc > 1) return false;
+    if (tab < 0 || tab > TAB_NONE || pf > 1 || (u != 2 && u != 4 && u != 8) || bc > 1) return false;
     c.tab = tab; c.u = u; c.prefetch = pf; c.block = bc ? 1024 : 256;
     return true;
 }
 
 template <int NF, int U, int TAB, bool STD, bool HOT, bool PF, bool EXTRAS, int BLOCK>
 static int launch_one(const MergeK& k, hipStream_t st) {
-    constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + (BLOCK / 64) * 2048;   // tables + transpose slabs
+    constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) > 0 ? (STD ? kStdTabBytes : TabInfo<TAB>::bytes) : 16;
     static_assert(lds <= kMaxLds, "LDS budget");
     auto kernel = merge_u8_fast<NF, U, TAB, STD, HOT, PF, EXTRAS, BLOCK>;
     if (lds > 48 * 1024) {
@@ -617,7 +602,7 @@ static int launch_one(const MergeK& k, hipStream_t st) {
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
     if (per_cu < 1) per_cu = 1;
-    const int64_t groups = k.n_elems / (U * 256);
+    const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
     const unsigned grid = stream_grid(groups, BLOCK / 64, per_cu);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, st, k);
     return launch_status();
@@ -644,35 +629,39 @@ static int launch_val_tab(const MergeK& k, const FastCfg& c, hipStream_t st) {
     }
 }
 
+// Units per group (U sub-units of 128 elements) of the production configurations:
+constexpr int kUVal = 2;     // val-only: 256 contiguous bytes per frame per wave iteration (tune: 134.7 us vs 139.9 at U = 4)
+constexpr int kUStd = 2;     // with std: the float64 std streams dominate; fewer registers
+
 template <int NF>
 static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, bool hot, hipStream_t st) {
     const bool extras = k.has_flat || k.out_sum_w;
     if (with_std) {
-        if (hot) return launch_one<NF, 1, TAB_PLAIN, true, true, false, true, 256>(k, st);
-        if (extras) return launch_one<NF, 1, TAB_PLAIN, true, false, false, true, 256>(k, st);
-        return launch_one<NF, 1, TAB_PLAIN, true, false, false, false, 256>(k, st);
+        if (hot) return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, true, 256>(k, st);
+        if (extras) return launch_one<NF, kUStd, TAB_PLAIN, true, false, false, true, 256>(k, st);
+        return launch_one<NF, kUStd, TAB_PLAIN, true, false, false, false, 256>(k, st);
     }
-    if (hot) return launch_one<NF, 2, TAB_FUSED, false, true, false, true, 256>(k, st);
-    if (extras) return launch_one<NF, 2, TAB_FUSED, false, false, false, true, 256>(k, st);
+    if (hot) return launch_one<NF, kUVal, TAB_FUSED, false, true, false, true, 256>(k, st);
+    if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, false, false, true, 256>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
         if (c.prefetch) {
-            if (c.u == 1) return launch_val_tab<NF, 1, true>(k, c, st);
             if (c.u == 2) return launch_val_tab<NF, 2, true>(k, c, st);
-            return launch_val_tab<NF, 4, true>(k, c, st);
+            if (c.u == 4) return launch_val_tab<NF, 4, true>(k, c, st);
+            return launch_val_tab<NF, 8, true>(k, c, st);
         }
-        if (c.u == 1) return launch_val_tab<NF, 1, false>(k, c, st);
         if (c.u == 2) return launch_val_tab<NF, 2, false>(k, c, st);
-        return launch_val_tab<NF, 4, false>(k, c, st);
+        if (c.u == 4) return launch_val_tab<NF, 4, false>(k, c, st);
+        return launch_val_tab<NF, 8, false>(k, c, st);
     } else {
-        return launch_one<NF, 2, TAB_FUSED, false, false, false, false, 256>(k, st);
+        return launch_one<NF, kUVal, TAB_FUSED, false, false, false, false, 256>(k, st);
     }
 }
 
 // elements per group of the configuration launch_fast_nf() will really use
 static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool hot, bool extras) {
-    if (with_std) return 256;
-    if (hot || extras || n_frames != HM_TUNE_NF) return 2 * 256;
-    return c.u * 256;
+    if (with_std) return kUStd * static_cast<int>(kSub);
+    if (hot || extras || n_frames != HM_TUNE_NF) return kUVal * static_cast<int>(kSub);
+    return c.u * static_cast<int>(kSub);
 }
 
 static int launch_generic(const MergeK& k, bool f64in, bool with_std, bool hot, hipStream_t st) {
@@ -779,9 +768,9 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     bool fast = !f64in && C == 3 && N <= 16 && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
-            fast = aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 4);
+            fast = aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 2);
             if (fast && with_std) fast = aligned(k.sd[i] + k.in_off, 16);
-            if (fast && k.dark[i]) fast = aligned(k.dark[i] + k.in_off, 4);
+            if (fast && k.dark[i]) fast = aligned(k.dark[i] + k.in_off, 2);
         }
         fast = fast && aligned(k.out_val, 16) && (!k.out_std || aligned(k.out_std, 16)) &&
                (!k.out_sum_w || aligned(k.out_sum_w, 16));
