@@ -32,6 +32,9 @@ WORKLOADS = {
     # name: (frames, H, W, with_std, corrections)
     "cfg2": (7, 4096, 4096, False, False),      # BASELINE.json configs[1] - the headline
     "cfg3": (7, 4096, 4096, True, True),        # configs[2]: + float64 std, dark hot-pixel maps, flat field
+    "cfg3std": (7, 4096, 4096, True, False),    # configs[2] without the corrections (std propagation only)
+    "cfg3flat": (7, 4096, 4096, True, "flat"),  # std + flat field
+    "cfg3hot": (7, 4096, 4096, True, "hot"),    # std + dark hot-pixel maps
     "cfg4tile": (15, 1024, 8192, False, False),  # configs[3]: one of 8 row tiles of 15 x 8192 x 8192 x 3
 }
 
@@ -56,6 +59,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-s", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the stack the CPU baseline merges")
     a = ap.parse_args()
 
@@ -83,9 +87,11 @@ def main():
     if corr:
         flat, flat_std, dark = synthetic_flat_dark(7 + rank, H, W, device=dev)
         x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
-        kw.update(flat=flat, flat_std=flat_std, ff_mean=engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy(),
-                  ff_std_mean=engine.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy(),
-                  darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, 0.05)] * n, median_k=3)
+        if corr in (True, "flat"):
+            kw.update(flat=flat, flat_std=flat_std, ff_mean=engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy(),
+                      ff_std_mean=engine.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy())
+        if corr in (True, "hot"):
+            kw.update(darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, 0.05)] * n, median_k=3)
     plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds, variant=a.variant, **kw)
     alg_bytes = plan.algorithmic_bytes
 
@@ -95,6 +101,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock pre-warm (untimed, like data generation): an idle MI355X needs a few hundred ms of load before it
+    # holds its sustained clock; without it the first launches of a short run measure the ramp, not the kernel
+    t_end = time.perf_counter() + a.prewarm_s
+    while time.perf_counter() < t_end:
+        for _ in range(50):
+            plan.launch()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         plan.launch()
     # HIP events on the launch stream (torch's current stream is the one hm_merge is given), bracketing the

@@ -1,24 +1,31 @@
 // hm_merge.hip - fused HDR merge for gfx950 (MI355X).
 //
-// Replaces, in one launch, the two passes of the reference's merge loop
+// Replaces, in one call, the two passes of the reference's merge loop
 // (modules/exposure_series.py:317-345 `_precalculate_sum_of_weights` and :347-397
 // `_compute_HDR_image_set`) together with the per-frame arithmetic they call:
 // apply_gaussian_weight (modules/measurand.py:606-618), linearize (:471-541), the optional hot-pixel
 // median (:543-557) and the optional flat-field normalisation (:559-604).
 //
-// The path is HBM-bandwidth bound (no MFMA): every input byte is read once with wide coalesced loads,
-// every output byte written once. Per (element, frame) the only arithmetic is a table gather, because
-// for 8-bit frames both the Gaussian weight and the ICRF depend on the DN alone; the 256-entry tables
-// (w, w*g per channel, ...) live in LDS. With N = 7 val-only frames the LDS gather rate, not HBM, is
-// the first ceiling, so the val-only kernel replicates the tables across LDS banks (TAB_* below).
+// The path is HBM-bandwidth bound (no MFMA): every input byte is read once with coalesced loads, every
+// output byte written once. Per (element, frame) the only arithmetic is a table gather, because for
+// 8-bit frames both the Gaussian weight and the ICRF depend on the DN alone; the 256-entry tables
+// (w, w*g per channel, ...) live in LDS.
 //
-// Two kernels:
-//   merge_u8_fast   C == 3, N <= 16 (compile-time), 2-byte-aligned uint8 frames; the bench path.
-//   merge_generic   anything else (float64 frames, other C, N <= 32, tails, unaligned tiles):
-//                   one element per thread, same arithmetic.
+// Kernels:
+//   merge_u8_fast     C == 3, N <= 16 (compile-time), 2-byte-aligned uint8 frames; the bench path.
+//   merge_generic     anything else (float64 frames, other C, N <= 32, tails, unaligned tiles):
+//                     one element per thread, the same operation sequence.
+//   merge_fixup_hot   dark-frame hot pixels (~1e-4 of the image): scans the dark maps and recomputes the
+//                     affected output elements with the k x k medians substituted. Keeping the rare,
+//                     divergent, register-hungry median out of the streaming kernels is worth 5x on
+//                     config 3 (3.6 ms -> under 1 ms); the scan reads each dark byte once, which is the
+//                     d*N term of the algorithmic byte count.
 #include "hm_common.h"
 
 namespace hm {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // kernel arguments (passed by value in the kernarg segment; all loads from it are scalar)
@@ -48,38 +55,6 @@ struct MergeK {
     int32_t n_frames, C, median_k, has_flat;
 };
 
-// ------------------------------------------------------------------------------------------------
-// rare path: k x k median of one channel around one pixel, 'reflect' at the true image edges.
-// Selection by counting (no local arrays -> no scratch): the median is the sample v with
-// #(x < v) <= m < #(x <= v), m = k*k/2.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __noinline__ T median_at(const T* __restrict__ buf, int64_t H, int64_t W, int C,
-                                    int64_t buf_row0, int64_t row, int64_t col, int c, int k) {
-    const int r = k / 2;
-    const int m = (k * k) / 2;
-    T best = buf[((row - buf_row0) * W + col) * C + c];
-    for (int py = -r; py <= r; ++py) {
-        const int64_t yy = reflect_index(row + py, H) - buf_row0;
-        for (int px = -r; px <= r; ++px) {
-            const int64_t xx = reflect_index(col + px, W);
-            const T v = buf[(yy * W + xx) * C + c];
-            int less = 0, leq = 0;
-            for (int qy = -r; qy <= r; ++qy) {
-                const int64_t y2 = reflect_index(row + qy, H) - buf_row0;
-                for (int qx = -r; qx <= r; ++qx) {
-                    const int64_t x2 = reflect_index(col + qx, W);
-                    const T u = buf[(y2 * W + x2) * C + c];
-                    less += (u < v);
-                    leq += (u <= v);
-                }
-            }
-            if (less <= m && m < leq) best = v;
-        }
-    }
-    return best;
-}
-
 __device__ __forceinline__ void elem_to_pixel(const MergeK& a, int64_t e, int64_t& row, int64_t& col, int& c) {
     const int64_t wc = a.W * a.C;
     row = a.row0 + e / wc;
@@ -88,154 +63,380 @@ __device__ __forceinline__ void elem_to_pixel(const MergeK& a, int64_t e, int64_
     c = static_cast<int>(rem % a.C);
 }
 
-// flat-field epilogue, modules/measurand.py:585-602, operation order kept
-__device__ __forceinline__ void flat_field_apply(const MergeK& a, int64_t e, int c, bool with_std,
-                                                 double& val, double& sd) {
-    const double F = a.flat_u8 ? static_cast<double>(a.flat_u8[e]) / 255.0 : a.flat_f64[e];
-    const double m = a.ff_mean[c];
+// flat-field epilogue on loaded operands, modules/measurand.py:585-602. The value keeps the reference's
+// operations, (val / F) * m (:602). The three variance terms (:586-596) each divide by F**2 or F**4 in the
+// reference; here 1/F**2 is formed once and multiplied (3 float64 divisions fewer per element; the std
+// moves by <= 2 ulp, its test tolerance is 1e-9).
+__device__ __forceinline__ void flat_field_math(double F, double sF, double m, double s, bool with_std,
+                                                double& val, double& sd) {
     if (with_std) {
-        const double sF = a.flat_std[e];
-        const double s = a.ff_std_mean[c];
-        const double F2 = F * F;
-        double u_acq = (sd * sd) / F2;
-        u_acq *= m * m;
-        double u_ff = (val * val) / (F2 * F2);
-        u_ff *= sF * sF;
-        u_ff *= m * m;
-        double u_ffm = (val * val) / F2;
-        u_ffm *= s * s;
+        const double iF2 = 1.0 / (F * F);
+        const double v2 = val * val;
+        const double u_acq = ((sd * sd) * iF2) * (m * m);
+        const double u_ff = ((v2 * (iF2 * iF2)) * (sF * sF)) * (m * m);
+        const double u_ffm = (v2 * iF2) * (s * s);
         sd = sqrt(u_acq + u_ff + u_ffm);
     }
     val = (val / F) * m;
 }
 
+__device__ __forceinline__ void flat_field_apply(const MergeK& a, int64_t e, int c, bool with_std,
+                                                 double& val, double& sd) {
+    const double F = a.flat_u8 ? static_cast<double>(a.flat_u8[e]) / 255.0 : a.flat_f64[e];
+    flat_field_math(F, with_std ? a.flat_std[e] : 0.0, a.ff_mean[c], a.ff_std_mean[c], with_std, val, sd);
+}
+
 // ------------------------------------------------------------------------------------------------
-// generic kernel: one element per thread, runtime N and C, uint8 or float64 frames.
-// LDS: w[256] dw[256] g[256*C] d[256*C]  (plain tables, <= 20 KB)
+// k x k median of one channel around one pixel, 'reflect' at the true image edges, computed by the
+// WHOLE WAVE for one wave-uniform pixel: lane p < k*k loads neighbour p (one parallel load instead of
+// k*k dependent ones), then every lane ranks its value against the others with k*k readlane
+// broadcasts; a lane whose value v satisfies #(x < v) <= m < #(x <= v), m = k*k/2, holds the median.
+// Must be called with all 64 lanes active and identical arguments.
 // ------------------------------------------------------------------------------------------------
-template <bool F64IN, bool STD, bool HOT>
-__global__ __launch_bounds__(256) void merge_generic(const MergeK a) {
-    __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
-    const int C = a.C;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        t_w[i] = (!F64IN) ? a.w_lut[i] : 0.0;
-        t_dw[i] = (!F64IN && STD) ? a.dw_lut[i] : 0.0;
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long bits = __double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(bits), l);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(static_cast<unsigned long long>(bits) >> 32), l);
+    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+
+template <typename T>
+__device__ __noinline__ T wave_median(const T* __restrict__ buf, int64_t H, int64_t W, int C,
+                                      int64_t buf_row0, int64_t row, int64_t col, int c, int k) {
+    const int lane = threadIdx.x & 63;
+    const int n = k * k, r = k / 2, m = n / 2;
+    const bool valid = lane < n;
+    const int p = valid ? lane : 0;
+    const int64_t yy = reflect_index(row + (p / k - r), H) - buf_row0;
+    const int64_t xx = reflect_index(col + (p % k - r), W);
+    const double v = static_cast<double>(buf[(yy * W + xx) * C + c]);   // uint8 -> double: exact, order-preserving
+    int less = 0, leq = 0;
+    for (int q = 0; q < n; ++q) {
+        const double u = readlane_f64(v, q);
+        less += (u < v);
+        leq += (u <= v);
     }
-    for (int i = threadIdx.x; i < 256 * C; i += blockDim.x) {
-        t_g[i] = a.icrf[i];
-        t_d[i] = STD ? a.icrf_diff[i] : 0.0;
+    const unsigned long long is_med = __ballot(valid && less <= m && m < leq);
+    const int src = __ffsll(static_cast<long long>(is_med)) - 1;        // non-empty for totally ordered input
+    return static_cast<T>(readlane_f64(v, src < 0 ? 0 : src));
+}
+
+// ------------------------------------------------------------------------------------------------
+// One output element: the reference arithmetic (exposure_series.py:340-394) in the operation sequence
+// shared by every kernel of this file, so a result does not depend on which kernel (or tiling) produced
+// it: S = sum_i w_i in frame order; 1/S and 1/S**2 formed once; the numerator of :388 accumulated with
+// fma and divided by S at the end; variance terms of :389 accumulated with fma.
+// COOP = false: plain per-thread evaluation, dark maps ignored (streaming kernels).
+// COOP = true : `e` is wave-uniform, every lane evaluates the same element and hot frames take their value
+//               from wave_median(); `store` selects the one lane that writes.
+// Tables: t_w/t_dw [256], t_g/t_d [256*C] in LDS.
+// ------------------------------------------------------------------------------------------------
+template <bool F64IN, bool STD, bool COOP>
+__device__ __forceinline__ void merge_one_element(const MergeK& a, const double* t_w, const double* t_dw,
+                                                  const double* t_g, const double* t_d, int64_t e, bool store) {
+    const int C = a.C, N = a.n_frames;
+    const int64_t ei = a.in_off + e;
+    const int c = static_cast<int>(e % C);
+    int64_t row = 0, col = 0; int cc = 0;
+    if (COOP) elem_to_pixel(a, e, row, col, cc);
+    auto is_hot = [&](int i) -> bool { return COOP && a.dark[i] && static_cast<int>(a.dark[i][ei]) >= a.dark_min[i]; };
+    auto value_f64 = [&](int i, bool hot) -> double {
+        const double* f = static_cast<const double*>(a.frame[i]);
+        if (COOP && hot) return wave_median(f, a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+        return f[ei];
+    };
+    auto value_u8 = [&](int i, bool hot) -> uint32_t {
+        const uint8_t* f = static_cast<const uint8_t*>(a.frame[i]);
+        if (COOP && hot) return wave_median(f, a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+        return f[ei];
+    };
+    // ---- pass 1: S = sum_i w_i (exposure_series.py:340) ----
+    double S = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const bool hot = is_hot(i);
+        double w;
+        if (F64IN) {
+            const double dv = value_f64(i, hot) - 0.5;
+            w = exp(-30.0 * (dv * dv));                                 // measurand.py:615
+        } else {
+            w = t_w[value_u8(i, hot)];
+        }
+        S = (i == 0) ? w : S + w;
     }
-    __syncthreads();
-    const int N = a.n_frames;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < a.n_elems; q += stride) {
-        const int64_t e = a.elem0 + q;          // element relative to row0
-        const int64_t ei = a.in_off + e;        // element inside the input buffers
-        const int c = static_cast<int>(e % C);
-        // ---- pass 1: S = sum_i w_i (exposure_series.py:340) ----
-        double S = 0.0;
-        for (int i = 0; i < N; ++i) {
-            bool hot = false;
-            if (HOT && a.dark[i]) hot = a.dark[i][ei] >= a.dark_min[i];
-            double w;
-            if (F64IN) {
-                double v = static_cast<const double*>(a.frame[i])[ei];
-                if (HOT && hot) {
-                    int64_t row, col; int cc; elem_to_pixel(a, e, row, col, cc);
-                    v = median_at(static_cast<const double*>(a.frame[i]), a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                }
-                const double dv = v - 0.5;
-                w = exp(-30.0 * (dv * dv));
-            } else {
-                uint8_t dn = static_cast<const uint8_t*>(a.frame[i])[ei];
-                if (HOT && hot) {
-                    int64_t row, col; int cc; elem_to_pixel(a, e, row, col, cc);
-                    dn = median_at(static_cast<const uint8_t*>(a.frame[i]), a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                }
-                w = t_w[dn];
-            }
-            S = (i == 0) ? w : S + w;
+    if (a.out_sum_w && store) a.out_sum_w[e] = S;
+    if (!a.out_val) return;
+    const double invS = 1.0 / S;
+    const double invS2 = 1.0 / (S * S);                                 // 1 / S**2, exposure_series.py:343
+    // ---- pass 2: exposure_series.py:382-389 ----
+    double acc = 0.0, var = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const bool hot = is_hot(i);
+        double w, dw;
+        uint32_t idx;
+        if (F64IN) {
+            const double v = value_f64(i, hot);
+            const double dv = v - 0.5;
+            w = exp(-30.0 * (dv * dv));
+            dw = (-60.0 * dv) * w;                                      // measurand.py:616
+            idx = static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;   // measurand.py:503
+        } else {
+            idx = value_u8(i, hot);
+            w = t_w[idx];
+            dw = STD ? t_dw[idx] : 0.0;
         }
-        if (a.out_sum_w) a.out_sum_w[e] = S;
-        if (!a.out_val) continue;
-        // Same operation sequence as merge_u8_fast, so a result does not depend on which kernel (or
-        // which tiling) produced it: reciprocals of S and S**2 (exposure_series.py:343) are formed once,
-        // the numerator of :388 is accumulated with fma and divided by S at the end.
-        const double invS = 1.0 / S;
-        const double invS2 = 1.0 / (S * S);
-        // ---- pass 2: exposure_series.py:382-389 ----
-        double acc = 0.0, var = 0.0;
-        for (int i = 0; i < N; ++i) {
-            bool hot = false;
-            if (HOT && a.dark[i]) hot = a.dark[i][ei] >= a.dark_min[i];
-            int64_t row = 0, col = 0; int cc = 0;
-            if (HOT && hot) elem_to_pixel(a, e, row, col, cc);
-            double w, dw;
-            uint32_t idx;
-            if (F64IN) {
-                double v = static_cast<const double*>(a.frame[i])[ei];
-                if (HOT && hot)
-                    v = median_at(static_cast<const double*>(a.frame[i]), a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                const double dv = v - 0.5;
-                w = exp(-30.0 * (dv * dv));
-                dw = (-60.0 * dv) * w;
-                idx = static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;   // measurand.py:503
-            } else {
-                uint8_t dn = static_cast<const uint8_t*>(a.frame[i])[ei];
-                if (HOT && hot)
-                    dn = median_at(static_cast<const uint8_t*>(a.frame[i]), a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                idx = dn;
-                w = t_w[dn];
-                dw = STD ? t_dw[dn] : 0.0;
-            }
-            const double g = t_g[idx * C + c];
-            const double it = a.inv_t[i];
-            const double wg = w * g;
-            acc = (i == 0) ? wg * it : fma(wg, it, acc);               // :388 numerator
-            if (STD) {
-                double s = a.sd[i][ei];
-                if (HOT && hot) s = median_at(a.sd[i], a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                const double dg = t_d[idx * C + c] * s;                // measurand.py:512
-                const double A = (dw * g + w * dg) * invS - ((dw * w) * g) * invS2;   // :389
-                const double term = (A * dg) * it;
-                var = (i == 0) ? term * term : fma(term, term, var);
-            }
+        const double g = t_g[idx * C + c];
+        const double it = a.inv_t[i];
+        const double wg = w * g;
+        acc = (i == 0) ? wg * it : fma(wg, it, acc);                    // :388 numerator
+        if (STD) {
+            double s;
+            if (COOP && hot) s = wave_median(a.sd[i], a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+            else s = a.sd[i][ei];
+            const double dg = t_d[idx * C + c] * s;                     // measurand.py:512
+            const double A = (dw * g + w * dg) * invS - ((dw * w) * g) * invS2;   // :389
+            const double term = (A * dg) * it;
+            var = (i == 0) ? term * term : fma(term, term, var);
         }
-        double val = acc / S;
-        double sd = STD ? sqrt(var) : 0.0;                             // :394
-        if (a.has_flat) flat_field_apply(a, e, c, STD, val, sd);
+    }
+    double val = acc / S;
+    double sd = STD ? sqrt(var) : 0.0;                                  // :394
+    if (a.has_flat) flat_field_apply(a, e, c, STD, val, sd);
+    if (store) {
         a.out_val[e] = val;
         if (STD) a.out_std[e] = sd;
     }
 }
 
+template <bool F64IN, bool STD>
+__device__ __forceinline__ void fill_plain_tables(const MergeK& a, double* t_w, double* t_dw, double* t_g, double* t_d) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        t_w[i] = (!F64IN) ? a.w_lut[i] : 0.0;
+        t_dw[i] = (!F64IN && STD) ? a.dw_lut[i] : 0.0;
+    }
+    for (int i = threadIdx.x; i < 256 * a.C; i += blockDim.x) {
+        t_g[i] = a.icrf[i];
+        t_d[i] = STD ? a.icrf_diff[i] : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// fast kernel: uint8 frames, C == 3, compile-time N, VEC consecutive elements per lane.
+// generic kernel: one element per thread, runtime N and C, uint8 or float64 frames.
 // ------------------------------------------------------------------------------------------------
-// LDS table layouts of the val-only kernel (entry = 8-byte double unless noted):
-//   TAB_PLAIN   w[256] | wg[256*3]                         8 KB   (random DNs: ~3.5-way bank conflicts)
-//   TAB_FUSED   {w, wg}[256*3] as 16-byte entries          12 KB  one ds_read_b128 per (element, frame)
-//   TAB_REP16   w and wg, 16 replicas each: entry q at q*128 + (lane&15)*8     32 + 96 = 128 KB
-//               lanes l and l+16 of a 32-lane LDS group share a replica -> at most 2-way conflicts
-//   TAB_REP32W  w private per lane of the group: dn*256 + (lane&31)*8 (64 KB, conflict-free),
-//               wg as TAB_REP16 (96 KB)                    160 KB = all of the CU's LDS
-//   TAB_FUSED8  {w, wg} 16-byte entries, 8 replicas: q*128 + (lane&7)*16       96 KB
-// The std kernel uses {w,dw}[256] and {g,d}[768] as 16-byte entries (16 KB), unreplicated: with the
-// float64 std streams it is HBM-bound by a wide margin.
-//   TAB_NONE    (tuning probe only, wrong results) no LDS gather at all: w, wg derived from the DN by a
-//               conversion - the HBM ceiling of this access pattern
-enum { TAB_PLAIN = 0, TAB_FUSED = 1, TAB_REP16 = 2, TAB_REP32W = 3, TAB_FUSED8 = 4, TAB_NONE = 5 };
+template <bool F64IN, bool STD>
+__global__ __launch_bounds__(256) void merge_generic(const MergeK a) {
+    __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
+    fill_plain_tables<F64IN, STD>(a, t_w, t_dw, t_g, t_d);
+    __syncthreads();
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < a.n_elems; q += stride)
+        merge_one_element<F64IN, STD, false>(a, t_w, t_dw, t_g, t_d, a.elem0 + q, true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hot-pixel fix-up.
+// fixup_element(): one wave recomputes one output element `e` (wave-uniform) with the frames spread over
+// the lanes - lane i < N owns frame i: its dark byte, its value and std are loaded in parallel (one memory
+// latency instead of N); the k x k medians of ALL hot frames are taken at once by sub-groups of k*k lanes
+// (floor(64 / k^2) frames per batch; ranks by ds_bpermute shuffles inside the sub-group); the per-frame
+// terms are then formed in parallel and accumulated with readlane broadcasts IN FRAME ORDER, i.e. with
+// exactly the operation sequence of merge_one_element(), so the fix-up is bit-identical to what a
+// streaming kernel would have produced had it been given the filtered frames.
+// ------------------------------------------------------------------------------------------------
+template <bool F64IN, bool STD>
+__device__ __forceinline__ void fixup_element(const MergeK& a, const double* t_w, const double* t_dw,
+                                           const double* t_g, const double* t_d, int64_t e) {
+    const int lane = threadIdx.x & 63;
+    const int C = a.C, N = a.n_frames;
+    const int64_t ei = a.in_off + e;
+    const int c = static_cast<int>(e % C);
+    int64_t row, col; int cc;
+    elem_to_pixel(a, e, row, col, cc);
+    const bool owner = lane < N;
+    const int fi = owner ? lane : 0;
+    // the lane's own frame: pointers picked with wave-uniform indices (a per-lane index into the kernarg
+    // struct would make hipcc spill the whole struct to scratch for every thread of the kernel)
+    const void* fr = a.frame[0];
+    const double* sp = a.sd[0];
+    const uint8_t* dk = a.dark[0];
+    int dmin = a.dark_min[0];
+    double it = a.inv_t[0];
+    for (int i = 1; i < N; ++i) {
+        const bool me = lane == i;
+        fr = me ? a.frame[i] : fr;
+        sp = me ? a.sd[i] : sp;
+        dk = me ? a.dark[i] : dk;
+        dmin = me ? a.dark_min[i] : dmin;
+        it = me ? a.inv_t[i] : it;
+    }
+    // --- parallel loads of the lane's own frame
+    const bool hot = owner && dk && static_cast<int>(dk[ei]) >= dmin;
+    double v = F64IN ? static_cast<const double*>(fr)[ei] : static_cast<double>(static_cast<const uint8_t*>(fr)[ei]);
+    double sdv = STD ? sp[ei] : 0.0;
+    // --- medians of the hot frames, floor(64 / k^2) frames per batch
+    const unsigned long long hotmask = __ballot(hot);
+    const int k = a.median_k, kk = k * k, r = k / 2, m = kk / 2;
+    const int B = 64 / kk;
+    const int sub = lane / kk, p = lane % kk;
+    for (int i0 = 0; i0 < N; i0 += B) {
+        if (((hotmask >> i0) & ((B >= 64 ? ~0ull : ((1ull << B) - 1)))) == 0) continue;          // wave-uniform
+        const int f = i0 + sub;
+        const bool part = sub < B && f < N && ((hotmask >> f) & 1ull);
+        const void* pf = a.frame[i0];
+        const double* ps = a.sd[i0];
+        for (int j = 1; j < B && i0 + j < N; ++j) {
+            pf = sub == j ? a.frame[i0 + j] : pf;
+            ps = sub == j ? a.sd[i0 + j] : ps;
+        }
+        const int64_t yy = reflect_index(row + (p / k - r), a.H) - a.buf_row0;
+        const int64_t xx = reflect_index(col + (p % k - r), a.W);
+        const int64_t ni = (yy * a.W + xx) * C + cc;
+        double nv = 0.0, ns = 0.0;
+        if (part) {
+            nv = F64IN ? static_cast<const double*>(pf)[ni] : static_cast<double>(static_cast<const uint8_t*>(pf)[ni]);
+            if (STD) ns = ps[ni];
+        }
+        int lv = 0, qv = 0, ls = 0, qs = 0;
+        for (int q = 0; q < kk; ++q) {
+            const int src = sub * kk + q;
+            const double uv = __shfl(nv, src, 64);
+            lv += (uv < nv); qv += (uv <= nv);
+            if (STD) { const double us = __shfl(ns, src, 64); ls += (us < ns); qs += (us <= ns); }
+        }
+        const unsigned long long medv = __ballot(part && lv <= m && m < qv);
+        const unsigned long long meds = STD ? __ballot(part && ls <= m && m < qs) : 0ull;
+        // owner lane of frame f picks the median out of its sub-group
+        const int osub = fi - i0;
+        const bool mine = hot && osub >= 0 && osub < B;
+        const unsigned long long gmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1);
+        const int sh = mine ? osub * kk : 0;
+        const unsigned long long gv = (medv >> sh) & gmask, gs = (meds >> sh) & gmask;
+        const int srcv = sh + (gv ? __ffsll(static_cast<long long>(gv)) - 1 : 0);
+        const int srcs = sh + (gs ? __ffsll(static_cast<long long>(gs)) - 1 : 0);
+        const double mv = __shfl(nv, srcv, 64);
+        const double ms = STD ? __shfl(ns, srcs, 64) : 0.0;
+        if (mine) { v = mv; if (STD) sdv = ms; }
+    }
+    // --- per-frame quantities, in parallel
+    double w = 0.0, dw = 0.0;
+    uint32_t idx = 0;
+    if (owner) {
+        if (F64IN) {
+            const double dv = v - 0.5;
+            w = exp(-30.0 * (dv * dv));
+            dw = (-60.0 * dv) * w;
+            idx = static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;
+        } else {
+            idx = static_cast<uint32_t>(v);
+            w = t_w[idx];
+            dw = STD ? t_dw[idx] : 0.0;
+        }
+    }
+    // --- S in frame order
+    double S = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double wi = readlane_f64(w, i);
+        S = (i == 0) ? wi : S + wi;
+    }
+    if (a.out_sum_w && lane == 0) a.out_sum_w[e] = S;
+    if (!a.out_val) return;
+    const double invS = 1.0 / S;
+    const double invS2 = 1.0 / (S * S);
+    const double g = t_g[idx * C + c];
+    const double wg = w * g;
+    double term = 0.0;
+    if (STD) {
+        const double dg = t_d[idx * C + c] * sdv;
+        const double A = (dw * g + w * dg) * invS - ((dw * w) * g) * invS2;
+        term = (A * dg) * it;
+    }
+    double acc = 0.0, var = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double wgi = readlane_f64(wg, i), iti = readlane_f64(it, i);
+        acc = (i == 0) ? wgi * iti : fma(wgi, iti, acc);
+        if (STD) {
+            const double ti = readlane_f64(term, i);
+            var = (i == 0) ? ti * ti : fma(ti, ti, var);
+        }
+    }
+    double val = acc / S;
+    double sd = STD ? sqrt(var) : 0.0;
+    if (a.has_flat) flat_field_apply(a, e, c, STD, val, sd);
+    if (lane == 0) {
+        a.out_val[e] = val;
+        if (STD) a.out_std[e] = sd;
+    }
+}
+
+// merge_fixup_hot: every lane scans 16 consecutive elements of every distinct dark map (one 16-byte load
+// when the address allows); elements with at least one hot frame are recomputed, one at a time, by the wave.
+template <bool F64IN, bool STD>
+__global__ __launch_bounds__(256) void merge_fixup_hot(const MergeK a) {
+    __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
+    fill_plain_tables<F64IN, STD>(a, t_w, t_dw, t_g, t_d);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (a.n_elems + 15) / 16;
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    // chunks are dealt 64 at a time to a wave, so the trip count is wave-uniform
+    for (int64_t cb = wave0 * 64; cb < n_chunks; cb += n_waves * 64) {
+        const int64_t chunk = cb + lane;
+        const int64_t e0 = a.elem0 + chunk * 16;                            // relative to row0
+        uint32_t hotbits = 0;
+        if (chunk < n_chunks) {
+            const int64_t left = a.elem0 + a.n_elems - e0;
+            const int cnt = left < 16 ? static_cast<int>(left) : 16;
+            for (int i = 0; i < a.n_frames; ++i) {
+                const uint8_t* d = a.dark[i];
+                if (!d) continue;
+                bool seen = false;                                          // same map + threshold as an earlier frame
+                for (int k = 0; k < i; ++k) seen = seen || (a.dark[k] == d && a.dark_min[k] == a.dark_min[i]);
+                if (seen) continue;
+                const uint8_t* p = d + a.in_off + e0;
+                const uint32_t thr = static_cast<uint32_t>(a.dark_min[i]);
+                if (cnt == 16 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) hotbits |= (((w4[b >> 2] >> (8 * (b & 3))) & 255u) >= thr) ? (1u << b) : 0u;
+                } else {
+                    for (int b = 0; b < cnt; ++b) hotbits |= (static_cast<uint32_t>(p[b]) >= thr) ? (1u << b) : 0u;
+                }
+            }
+        }
+        unsigned long long pending = __ballot(hotbits != 0);
+        while (pending) {                                                    // rare
+            const int src = __ffsll(static_cast<long long>(pending)) - 1;
+            pending &= pending - 1;
+            uint32_t bits = __builtin_amdgcn_readlane(hotbits, src);
+            const int64_t base = a.elem0 + (cb + src) * 16;
+            while (bits) {
+                const int b = __ffs(static_cast<int>(bits)) - 1;
+                bits &= bits - 1;
+                fixup_element<F64IN, STD>(a, t_w, t_dw, t_g, t_d, base + b);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast kernel: uint8 frames, C == 3, compile-time N.
+// ------------------------------------------------------------------------------------------------
+// LDS table layouts of the val-only kernel:
+//   TAB_PLAIN   w[256] | wg[256*3]  (8-byte entries, two ds_read_b64 per (element, frame))        8 KB
+//   TAB_FUSED   {w, wg}[256*3] as 16-byte entries, one ds_read_b128 per (element, frame)          12 KB
+//   TAB_NONE    (tuning probe only, wrong results) no gather at all: the HBM ceiling of the access pattern
+// Replicating the tables across banks was measured and dropped: only a full private copy
+// per lane of an LDS lane group removes the ~2.4-way conflicts random DNs cause, and that needs 64 KB per
+// 256-entry float64 table, i.e. one workgroup per CU, which loses more latency hiding than it gains.
+// The std kernel uses {w,dw}[256] and {g,d}[768] as 16-byte entries (16 KB).
+enum { TAB_PLAIN = 0, TAB_FUSED = 1, TAB_NONE = 5 };
 
 template <int TAB> struct TabInfo;
-template <> struct TabInfo<TAB_PLAIN>  { static constexpr int bytes = 8 * 256 * 4; };
-template <> struct TabInfo<TAB_FUSED>  { static constexpr int bytes = 16 * 768; };
-template <> struct TabInfo<TAB_REP16>  { static constexpr int bytes = 128 * 256 + 128 * 768; };
-template <> struct TabInfo<TAB_REP32W> { static constexpr int bytes = 256 * 256 + 128 * 768; };
-template <> struct TabInfo<TAB_FUSED8> { static constexpr int bytes = 128 * 768; };
-template <> struct TabInfo<TAB_NONE>   { static constexpr int bytes = 0; };
+template <> struct TabInfo<TAB_PLAIN> { static constexpr int bytes = 8 * 256 * 4; };
+template <> struct TabInfo<TAB_FUSED> { static constexpr int bytes = 16 * 768; };
+template <> struct TabInfo<TAB_NONE>  { static constexpr int bytes = 16; };
 constexpr int kStdTabBytes = 16 * 256 + 16 * 768;
-
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p));
@@ -245,7 +446,6 @@ __device__ __forceinline__ void store2(double* p, double x, double y) {
     __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(p));
 }
 
-// fill the val-only tables; blockDim-agnostic
 template <int TAB>
 __device__ __forceinline__ void fill_val_tables(char* lds, const MergeK& a) {
     constexpr int C = 3;
@@ -258,65 +458,27 @@ __device__ __forceinline__ void fill_val_tables(char* lds, const MergeK& a) {
             double* t = reinterpret_cast<double*>(lds);
             if (q % C == 0) t[dn] = w;
             t[256 + q] = wg;
-        } else if constexpr (TAB == TAB_FUSED) {
-            double2* t = reinterpret_cast<double2*>(lds);
-            t[q] = double2{w, wg};
-        } else if constexpr (TAB == TAB_REP16) {
-            double* tw = reinterpret_cast<double*>(lds);
-            double* tg = reinterpret_cast<double*>(lds + 128 * 256);
-            for (int r = 0; r < 16; ++r) {
-                if (q % C == 0) tw[dn * 16 + r] = w;
-                tg[q * 16 + r] = wg;
-            }
-        } else if constexpr (TAB == TAB_REP32W) {
-            double* tw = reinterpret_cast<double*>(lds);
-            double* tg = reinterpret_cast<double*>(lds + 256 * 256);
-            for (int r = 0; r < 32; ++r)
-                if (q % C == 0) tw[dn * 32 + r] = w;
-            for (int r = 0; r < 16; ++r) tg[q * 16 + r] = wg;
-        } else if constexpr (TAB == TAB_FUSED8) {
-            double2* t = reinterpret_cast<double2*>(lds);
-            for (int r = 0; r < 8; ++r) t[q * 8 + r] = double2{w, wg};
+        } else {
+            reinterpret_cast<double2*>(lds)[q] = double2{w, wg};
         }
     }
 }
 
-// gather {w, wg} for DN `dn`, channel byte offset prepared by lane_coff<TAB>()
 template <int TAB>
-__device__ __forceinline__ uint32_t lane_woff() {
-    const uint32_t lane = threadIdx.x & 63u;
-    if constexpr (TAB == TAB_REP16) return (lane & 15u) * 8u;
-    if constexpr (TAB == TAB_REP32W) return (lane & 31u) * 8u;
-    return 0u;
-}
-template <int TAB>
-__device__ __forceinline__ uint32_t lane_coff(int c) {
-    const uint32_t lane = threadIdx.x & 63u;
+__device__ __forceinline__ uint32_t chan_off(uint32_t c) {
     if constexpr (TAB == TAB_PLAIN) return 2048u + c * 8u;
     if constexpr (TAB == TAB_FUSED) return c * 16u;
-    if constexpr (TAB == TAB_REP16) return 128u * 256u + c * 128u + (lane & 15u) * 8u;
-    if constexpr (TAB == TAB_REP32W) return 256u * 256u + c * 128u + (lane & 15u) * 8u;
-    return c * 128u + (lane & 7u) * 16u;   // TAB_FUSED8
+    return c;
 }
 template <int TAB>
-__device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_t woff, uint32_t coff,
-                                           double& w, double& wg) {
+__device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_t coff, double& w, double& wg) {
     if constexpr (TAB == TAB_NONE) {
         w = static_cast<double>(dn + 1u); wg = static_cast<double>(dn + coff);
     } else if constexpr (TAB == TAB_PLAIN) {
         w = *reinterpret_cast<const double*>(lds + dn * 8u);
         wg = *reinterpret_cast<const double*>(lds + dn * 24u + coff);
-    } else if constexpr (TAB == TAB_FUSED) {
-        const double2 t = *reinterpret_cast<const double2*>(lds + dn * 48u + coff);
-        w = t.x; wg = t.y;
-    } else if constexpr (TAB == TAB_REP16) {
-        w = *reinterpret_cast<const double*>(lds + dn * 128u + woff);
-        wg = *reinterpret_cast<const double*>(lds + dn * 384u + coff);
-    } else if constexpr (TAB == TAB_REP32W) {
-        w = *reinterpret_cast<const double*>(lds + dn * 256u + woff);
-        wg = *reinterpret_cast<const double*>(lds + dn * 384u + coff);
     } else {
-        const double2 t = *reinterpret_cast<const double2*>(lds + dn * 384u + coff);
+        const double2 t = *reinterpret_cast<const double2*>(lds + dn * 48u + coff);
         w = t.x; wg = t.y;
     }
 }
@@ -325,8 +487,7 @@ __device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_
 // behind it): a wave owns "groups" of U * 128 consecutive elements. In a 128-element sub-unit lane l
 // handles elements 2l and 2l+1:
 //   * input: one global_load_ushort per (frame, sub-unit), 128 contiguous bytes per wave instruction,
-//     immediate offsets 128*s off one scalar base; with U = 4 a wave streams 512 contiguous bytes per
-//     frame, the span that measured best for this 7-in / 1-out traffic shape;
+//     immediate offsets 128*s off one scalar base;
 //   * output: lane l owns the 16 contiguous bytes of elements 2l, 2l+1, so every store instruction is
 //     one fully contiguous 1 KB global_store_dwordx4 (nontemporal) - no cross-lane transposition.
 //     (Store instructions must cover whole 128-byte lines: 4 elements per lane stored directly is a
@@ -345,7 +506,7 @@ __device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_
 
 constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 
-template <int NF, int U, int TAB, bool STD, bool HOT, bool PREFETCH, bool EXTRAS, int BLOCK>
+template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool EXTRAS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int C = 3;
@@ -366,7 +527,6 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     constexpr uint32_t WPB = BLOCK / 64;
     const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / GROUP);
     const uint32_t gstride = gridDim.x * WPB;
-    const uint32_t woff = lane_woff<TAB>();
 
     uint32_t g = blockIdx.x * WPB + wave;                                   // wave-uniform
     uint32_t raw[NF][U];
@@ -397,41 +557,30 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             const int64_t sbase = gbase + kSub * s;                         // scalar
-            const int64_t e0 = sbase + lane2;
             const uint32_t c0 = (2u * (g * U + s + lane)) % 3u;
+            const uint32_t c1 = (c0 + 1u) % 3u;
+            const uint32_t coffs[2] = {STD ? c0 * 16u : chan_off<TAB>(c0), STD ? c1 * 16u : chan_off<TAB>(c1)};
+            double* ov = a.out_val + sbase;                                   // scalar bases
+            double* osw = EXTRAS && a.out_sum_w ? a.out_sum_w + sbase : nullptr;
 
-            // hot-pixel prologue (rare): replace the DN by the k x k median of its frame
-            uint32_t hotmask[NF];
-            if constexpr (HOT) {
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    hotmask[i] = 0;
-                    if (a.dark[i]) {
-                        const uint32_t dr = ld_u16(a.dark[i] + a.in_off + sbase + lane2);
-                        const uint32_t thr = static_cast<uint32_t>(a.dark_min[i]);
-                        hotmask[i] = ((dr & 255u) >= thr ? 1u : 0u) | ((dr >> 8) >= thr ? 2u : 0u);
-                        if (hotmask[i]) {
-                            for (int j = 0; j < 2; ++j) {
-                                if (hotmask[i] & (1u << j)) {
-                                    int64_t row, col; int cc; elem_to_pixel(a, e0 + j, row, col, cc);
-                                    const uint32_t md = median_at(static_cast<const uint8_t*>(a.frame[i]), a.H, a.W, C,
-                                                                  a.buf_row0, row, col, cc, a.median_k);
-                                    cur[i][s] = (cur[i][s] & ~(255u << (8 * j))) | (md << (8 * j));
-                                }
-                            }
-                        }
+            // flat-field operands of the lane's two elements (one ushort / 16-byte loads)
+            double F[2] = {1.0, 1.0}, sF[2] = {0.0, 0.0};
+            if constexpr (EXTRAS) {
+                if (a.has_flat) {
+                    if (a.flat_u8) {
+                        const uint32_t f = ld_u16(a.flat_u8 + sbase + lane2);
+                        F[0] = static_cast<double>(f & 255u) / 255.0;
+                        F[1] = static_cast<double>(f >> 8) / 255.0;
+                    } else {
+                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(a.flat_f64 + sbase + lane2));
+                        F[0] = f.x; F[1] = f.y;
+                    }
+                    if (STD) {
+                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(a.flat_std + sbase + lane2));
+                        sF[0] = f.x; sF[1] = f.y;
                     }
                 }
             }
-
-            uint32_t coffs[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t c = (c0 + k) % 3u;
-                coffs[k] = STD ? c * 16u : lane_coff<TAB>(static_cast<int>(c));
-            }
-            double* ov = a.out_val + sbase;                                   // scalar bases
-            double* osw = EXTRAS && a.out_sum_w ? a.out_sum_w + sbase : nullptr;
 
             if constexpr (!STD) {
                 double S[2], acc[2];
@@ -442,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                     for (int j = 0; j < 2; ++j) {
                         const uint32_t dn = j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8);
                         double w, wg;
-                        gather_val<TAB>(lds, dn, woff, coffs[j], w, wg);
+                        gather_val<TAB>(lds, dn, coffs[j], w, wg);
                         if (i == 0) { S[j] = w; acc[j] = wg * it; }
                         else {
                             S[j] += w;                               // exposure_series.py:340
@@ -461,11 +610,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 for (int j = 0; j < 2; ++j) val[j] = acc[j] / S[j];
                 if constexpr (EXTRAS) {
                     if (a.has_flat) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            double dummy = 0.0;
-                            flat_field_apply(a, e0 + j, static_cast<int>((c0 + j) % 3u), false, val[j], dummy);
-                        }
+                        double dummy = 0.0;
+                        flat_field_math(F[0], 0.0, a.ff_mean[c0], 0.0, false, val[0], dummy);
+                        flat_field_math(F[1], 0.0, a.ff_mean[c1], 0.0, false, val[1], dummy);
                     }
                     if (osw) store2(osw + lane2, S[0], S[1]);
                 }
@@ -495,28 +642,14 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 for (int i = 0; i < NF; ++i) {
                     const double it = a.inv_t[i];
                     const double* sp = a.sd[i] + a.in_off + sbase;                               // scalar base
-                    double sdv[2];
-                    {
-                        const f64x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sp + lane2));
-                        sdv[0] = v0.x; sdv[1] = v0.y;
-                    }
-                    if constexpr (HOT) {
-                        if (hotmask[i]) {
-                            for (int j = 0; j < 2; ++j) {
-                                if (hotmask[i] & (1u << j)) {
-                                    int64_t row, col; int cc; elem_to_pixel(a, e0 + j, row, col, cc);
-                                    sdv[j] = median_at(a.sd[i], a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
-                                }
-                            }
-                        }
-                    }
+                    const f64x2 sdv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sp + lane2));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const uint32_t dn = j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8);
                         const double2 wdw = t_wdw[dn];
                         const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
                         const double w = wdw.x, dw = wdw.y, gg = gd.x;
-                        const double dg = gd.y * sdv[j];                                        // measurand.py:512
+                        const double dg = gd.y * (j == 0 ? sdv.x : sdv.y);                       // measurand.py:512
                         const double A = (dw * gg + w * dg) * invS[j] - ((dw * w) * gg) * invS2[j];   // :389
                         const double term = (A * dg) * it;
                         if (i == 0) { acc[j] = (w * gg) * it; var[j] = term * term; }
@@ -539,9 +672,8 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 }
                 if constexpr (EXTRAS) {
                     if (a.has_flat) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            flat_field_apply(a, e0 + j, static_cast<int>((c0 + j) % 3u), true, val[j], so[j]);
+                        flat_field_math(F[0], sF[0], a.ff_mean[c0], a.ff_std_mean[c0], true, val[0], so[0]);
+                        flat_field_math(F[1], sF[1], a.ff_mean[c1], a.ff_std_mean[c1], true, val[1], so[1]);
                     }
                     if (osw) store2(osw + lane2, S[0], S[1]);
                 }
@@ -573,35 +705,30 @@ int cu_count() {
 //   variant = 1000 * TAB + 100 * PREFETCH + 10 * U + BLOCK_CODE     U in {2,4,8}; BLOCK_CODE: 0 -> 256 threads, 1 -> 1024
 struct FastCfg { int tab, u, prefetch, block; };
 
+// Units per group (U sub-units of 128 elements) of the production configurations:
+constexpr int kUVal = 2;     // val-only: 256 contiguous bytes per frame per wave iteration (tune: 134.7 us vs 139.9 at U = 4)
+constexpr int kUStd = 2;     // with std: the float64 std streams dominate
+
 static FastCfg default_cfg(bool with_std) {
-    if (with_std) return FastCfg{TAB_PLAIN, 2, 0, 256};
-    return FastCfg{TAB_FUSED, 2, 0, 256};     // tools/tune_merge.py, tools/mergelab.hip, profiles/
+    if (with_std) return FastCfg{TAB_PLAIN, kUStd, 0, 256};
+    return FastCfg{TAB_FUSED, kUVal, 0, 256};     // tools/tune_merge.py, tools/mergelab.hip, profiles/
 }
 
 static bool decode_variant(int variant, bool with_std, FastCfg& c) {
     c = default_cfg(with_std);
     if (variant <= 0 || with_std) return true;
     const int tab = variant / 1000, pf = (variant / 100) % 10, u = (variant / 10) % 10, bc = variant % 10;
-    if (tab < 0 || tab > TAB_NONE || pf > 1 || (u != 2 && u != 4 && u != 8) || bc > 1) return false;
+    if ((tab != TAB_PLAIN && tab != TAB_FUSED && tab != TAB_NONE) || pf > 1 || (u != 2 && u != 4 && u != 8) || bc > 1) return false;
     c.tab = tab; c.u = u; c.prefetch = pf; c.block = bc ? 1024 : 256;
     return true;
 }
 
-template <int NF, int U, int TAB, bool STD, bool HOT, bool PF, bool EXTRAS, int BLOCK>
+template <int NF, int U, int TAB, bool STD, bool PF, bool EXTRAS, int BLOCK>
 static int launch_one(const MergeK& k, hipStream_t st) {
-    constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) > 0 ? (STD ? kStdTabBytes : TabInfo<TAB>::bytes) : 16;
-    static_assert(lds <= kMaxLds, "LDS budget");
-    auto kernel = merge_u8_fast<NF, U, TAB, STD, HOT, PF, EXTRAS, BLOCK>;
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess) {
-            (void)hipGetLastError();
-            return HM_ELAUNCH;
-        }
-    }
+    constexpr int lds = STD ? kStdTabBytes : TabInfo<TAB>::bytes;
+    auto kernel = merge_u8_fast<NF, U, TAB, STD, PF, EXTRAS, BLOCK>;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
-    if (per_cu < 1) per_cu = 1;
     const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
     const unsigned grid = stream_grid(groups, BLOCK / 64, per_cu);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, st, k);
@@ -609,40 +736,32 @@ static int launch_one(const MergeK& k, hipStream_t st) {
 }
 
 #ifndef HM_TUNE_NF
-#define HM_TUNE_NF 0      /* build with -DHM_TUNE_NF=7 to get the full variant matrix for N = 7 */
+#define HM_TUNE_NF 0      /* build with -DHM_TUNE_NF=7 to get the variant matrix for N = 7 */
 #endif
 
 template <int NF, int U, int TAB, bool PF>
 static int launch_val_blk(const MergeK& k, const FastCfg& c, hipStream_t st) {
-    if (c.block == 256) return launch_one<NF, U, TAB, false, false, PF, false, 256>(k, st);
-    return launch_one<NF, U, TAB, false, false, PF, false, 1024>(k, st);
+    if (c.block == 256) return launch_one<NF, U, TAB, false, PF, false, 256>(k, st);
+    return launch_one<NF, U, TAB, false, PF, false, 1024>(k, st);
 }
 
 template <int NF, int U, bool PF>
 static int launch_val_tab(const MergeK& k, const FastCfg& c, hipStream_t st) {
     switch (c.tab) {
-        case TAB_PLAIN:  return launch_val_blk<NF, U, TAB_PLAIN, PF>(k, c, st);
-        case TAB_FUSED:  return launch_val_blk<NF, U, TAB_FUSED, PF>(k, c, st);
-        case TAB_REP16:  return launch_val_blk<NF, U, TAB_REP16, PF>(k, c, st);
-        case TAB_FUSED8: return launch_val_blk<NF, U, TAB_FUSED8, PF>(k, c, st);
-        default:         return launch_val_blk<NF, U, TAB_NONE, PF>(k, c, st);
+        case TAB_PLAIN: return launch_val_blk<NF, U, TAB_PLAIN, PF>(k, c, st);
+        case TAB_FUSED: return launch_val_blk<NF, U, TAB_FUSED, PF>(k, c, st);
+        default:        return launch_val_blk<NF, U, TAB_NONE, PF>(k, c, st);
     }
 }
 
-// Units per group (U sub-units of 128 elements) of the production configurations:
-constexpr int kUVal = 2;     // val-only: 256 contiguous bytes per frame per wave iteration (tune: 134.7 us vs 139.9 at U = 4)
-constexpr int kUStd = 2;     // with std: the float64 std streams dominate; fewer registers
-
 template <int NF>
-static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, bool hot, hipStream_t st) {
+static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipStream_t st) {
     const bool extras = k.has_flat || k.out_sum_w;
     if (with_std) {
-        if (hot) return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, true, 256>(k, st);
-        if (extras) return launch_one<NF, kUStd, TAB_PLAIN, true, false, false, true, 256>(k, st);
-        return launch_one<NF, kUStd, TAB_PLAIN, true, false, false, false, 256>(k, st);
+        if (extras) return launch_one<NF, kUStd, TAB_PLAIN, true, false, true, 256>(k, st);
+        return launch_one<NF, kUStd, TAB_PLAIN, true, false, false, 256>(k, st);
     }
-    if (hot) return launch_one<NF, kUVal, TAB_FUSED, false, true, false, true, 256>(k, st);
-    if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, false, false, true, 256>(k, st);
+    if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, false, true, 256>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
         if (c.prefetch) {
             if (c.u == 2) return launch_val_tab<NF, 2, true>(k, c, st);
@@ -653,28 +772,33 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, bool
         if (c.u == 4) return launch_val_tab<NF, 4, false>(k, c, st);
         return launch_val_tab<NF, 8, false>(k, c, st);
     } else {
-        return launch_one<NF, kUVal, TAB_FUSED, false, false, false, false, 256>(k, st);
+        return launch_one<NF, kUVal, TAB_FUSED, false, false, false, 256>(k, st);
     }
 }
 
 // elements per group of the configuration launch_fast_nf() will really use
-static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool hot, bool extras) {
+static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool extras) {
     if (with_std) return kUStd * static_cast<int>(kSub);
-    if (hot || extras || n_frames != HM_TUNE_NF) return kUVal * static_cast<int>(kSub);
+    if (extras || n_frames != HM_TUNE_NF) return kUVal * static_cast<int>(kSub);
     return c.u * static_cast<int>(kSub);
 }
 
-static int launch_generic(const MergeK& k, bool f64in, bool with_std, bool hot, hipStream_t st) {
+static int launch_generic(const MergeK& k, bool f64in, bool with_std, hipStream_t st) {
     const unsigned grid = stream_grid(k.n_elems, 256, 8);
-#define HM_GEN(F, S, H) hipLaunchKernelGGL((merge_generic<F, S, H>), dim3(grid), dim3(256), 0, st, k)
-    if (f64in) {
-        if (with_std) { if (hot) HM_GEN(true, true, true); else HM_GEN(true, true, false); }
-        else          { if (hot) HM_GEN(true, false, true); else HM_GEN(true, false, false); }
-    } else {
-        if (with_std) { if (hot) HM_GEN(false, true, true); else HM_GEN(false, true, false); }
-        else          { if (hot) HM_GEN(false, false, true); else HM_GEN(false, false, false); }
-    }
+#define HM_GEN(F, S) hipLaunchKernelGGL((merge_generic<F, S>), dim3(grid), dim3(256), 0, st, k)
+    if (f64in) { if (with_std) HM_GEN(true, true); else HM_GEN(true, false); }
+    else       { if (with_std) HM_GEN(false, true); else HM_GEN(false, false); }
 #undef HM_GEN
+    return launch_status();
+}
+
+static int launch_fixup(const MergeK& k, bool f64in, bool with_std, hipStream_t st) {
+    const int64_t chunks = (k.n_elems + 15) / 16;
+    const unsigned grid = stream_grid(chunks, 256, 8);
+#define HM_FIX(F, S) hipLaunchKernelGGL((merge_fixup_hot<F, S>), dim3(grid), dim3(256), 0, st, k)
+    if (f64in) { if (with_std) HM_FIX(true, true); else HM_FIX(true, false); }
+    else       { if (with_std) HM_FIX(false, true); else HM_FIX(false, false); }
+#undef HM_FIX
     return launch_status();
 }
 
@@ -762,7 +886,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     k.n_frames = N; k.C = C; k.median_k = hot ? g->median_k : 3; k.has_flat = flat ? 1 : 0;
     hipStream_t st = as_stream(stream);
 
-    // ---- fast path eligibility ----
+    // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
     if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
     bool fast = !f64in && C == 3 && N <= 16 && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
@@ -770,32 +894,38 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
         for (int i = 0; i < N && fast; ++i) {
             fast = aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 2);
             if (fast && with_std) fast = aligned(k.sd[i] + k.in_off, 16);
-            if (fast && k.dark[i]) fast = aligned(k.dark[i] + k.in_off, 2);
         }
         fast = fast && aligned(k.out_val, 16) && (!k.out_std || aligned(k.out_std, 16)) &&
                (!k.out_sum_w || aligned(k.out_sum_w, 16));
+        if (fast && flat)
+            fast = (k.flat_u8 ? aligned(k.flat_u8, 2) : aligned(k.flat_f64, 16)) && (!with_std || aligned(k.flat_std, 16));
     }
-    if (!fast) return launch_generic(k, f64in, with_std, hot, st);
-
-    const int64_t grp = fast_group_elems(N, cfg, with_std, hot, flat || g->out_sum_w);
-    const int64_t body = (E / grp) * grp;
     int rc = HM_OK;
-    if (body > 0) {
-        MergeK kb = k;
-        kb.n_elems = body;
-        switch (N) {
-#define HM_CASE(n) case n: rc = launch_fast_nf<n>(kb, cfg, with_std, hot, st); break;
-            HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
-            HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
+    if (!fast) {
+        rc = launch_generic(k, f64in, with_std, st);
+    } else {
+        const int64_t grp = fast_group_elems(N, cfg, with_std, flat || g->out_sum_w);
+        const int64_t body = (E / grp) * grp;
+        if (body > 0) {
+            MergeK kb = k;
+            kb.n_elems = body;
+            switch (N) {
+#define HM_CASE(n) case n: rc = launch_fast_nf<n>(kb, cfg, with_std, st); break;
+                HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
+                HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
 #undef HM_CASE
-            default: return HM_EUNSUPPORTED;
+                default: return HM_EUNSUPPORTED;
+            }
+            if (rc != HM_OK) return rc;
         }
-        if (rc != HM_OK) return rc;
+        if (body < E) {                                    // tail: less than one group
+            MergeK kt = k;
+            kt.elem0 = body; kt.n_elems = E - body;
+            rc = launch_generic(kt, false, with_std, st);
+        }
     }
-    if (body < E) {                                    // tail: less than one group
-        MergeK kt = k;
-        kt.elem0 = body; kt.n_elems = E - body;
-        rc = launch_generic(kt, false, with_std, hot, st);
-    }
+    if (rc != HM_OK) return rc;
+    // ---- hot-pixel fix-up pass (stream-ordered after the streaming pass: it overwrites the affected elements)
+    if (hot) rc = launch_fixup(k, f64in, with_std, st);
     return rc;
 }

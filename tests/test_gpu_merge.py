@@ -232,6 +232,36 @@ def test_merge_row_tiles_with_halo(eng):
     assert np.array_equal(std, host(whole["std"]))
 
 
+@pytest.mark.parametrize("n,k,f64", [(15, 5, False), (9, 7, False), (7, 3, True), (32, 3, False), (3, 5, True)])
+def test_hot_pixel_fixup_batches(eng, n, k, f64):
+    """The hot-pixel fix-up takes floor(64 / k^2) frames' medians per batch (k = 3: 7, k = 5: 2, k = 7: 1):
+    cover several batches, float64 frames, N up to 32, adjacent hot pixels, image corners and edges."""
+    rng = np.random.default_rng(100 * n + k)
+    h, w = 13, 11
+    frames, stds, t = orc.synthetic_stack(50 + n, n, h, w, with_std=True)
+    if f64:
+        frames = [orc.unit_from_u8(f) + rng.random(f.shape) * 1e-3 for f in frames]
+    icrf, diff = orc.synthetic_icrf()
+    darks, mins, odarks = [], [], []
+    for i in range(n):
+        if i % 3 == 1:
+            darks.append(None); mins.append(256); odarks.append(None)
+            continue
+        d = rng.integers(0, 10, size=(h, w, 3)).astype(np.uint8)
+        d[rng.random((h, w, 3)) < 0.06] = 200
+        d[0, 0, i % 3] = 255; d[h - 1, w - 1, (i + 1) % 3] = 255; d[0, w - 1, 0] = 255; d[h // 2, 0, 1] = 255
+        darks.append(dev(d)); mins.append(100); odarks.append(orc.unit_from_u8(d))
+    ref = orc.merge(frames, t, icrf, diff, stds=stds, darks=odarks, dark_threshold=99.5 / 255, median_k=k)
+    out = eng.merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds], darks=darks, dark_min=mins, median_k=k)
+    close(host(out["val"]), ref["val"], F64_RTOL if f64 else VAL_RTOL)
+    close(host(out["std"]), ref["std"], STD_RTOL)
+    # val-only with the same hot maps
+    ref = orc.merge(frames, t, icrf, diff, darks=odarks, dark_threshold=99.5 / 255, median_k=k)
+    out = eng.merge([dev(f) for f in frames], t, icrf, diff, darks=darks, dark_min=mins, median_k=k, want_sum_w=True)
+    close(host(out["val"]), ref["val"], F64_RTOL if f64 else VAL_RTOL)
+    close(host(out["sum_w"]), ref["S"], 1e-13)
+
+
 def test_merge_argument_errors(eng):
     f = dev(np.zeros((4, 4, 3), np.uint8))
     icrf, diff = orc.synthetic_icrf()
