@@ -707,17 +707,22 @@ struct FastCfg { int tab, u, prefetch, block; };
 
 // Units per group (U sub-units of 128 elements) of the production configurations:
 constexpr int kUVal = 2;     // val-only: 256 contiguous bytes per frame per wave iteration (tune: 134.7 us vs 139.9 at U = 4)
-constexpr int kUStd = 2;     // with std: the float64 std streams dominate
+constexpr int kUStd = 1;     // with std: one 128-element sub-unit per iteration + prefetch (tune: 684 us vs 753 at U = 2, no prefetch)
 
 static FastCfg default_cfg(bool with_std) {
-    if (with_std) return FastCfg{TAB_PLAIN, kUStd, 0, 256};
+    if (with_std) return FastCfg{TAB_PLAIN, kUStd, 1, 256};
     return FastCfg{TAB_FUSED, kUVal, 0, 256};     // tools/tune_merge.py, tools/mergelab.hip, profiles/
 }
 
 static bool decode_variant(int variant, bool with_std, FastCfg& c) {
     c = default_cfg(with_std);
-    if (variant <= 0 || with_std) return true;
+    if (variant <= 0) return true;
     const int tab = variant / 1000, pf = (variant / 100) % 10, u = (variant / 10) % 10, bc = variant % 10;
+    if (with_std) {                                   // std kernel: only U (1, 2, 4) and PREFETCH are tunable
+        if (pf > 1 || (u != 1 && u != 2 && u != 4)) return false;
+        c.u = u; c.prefetch = pf;
+        return true;
+    }
     if ((tab != TAB_PLAIN && tab != TAB_FUSED && tab != TAB_NONE) || pf > 1 || (u != 2 && u != 4 && u != 8) || bc > 1) return false;
     c.tab = tab; c.u = u; c.prefetch = pf; c.block = bc ? 1024 : 256;
     return true;
@@ -758,8 +763,18 @@ template <int NF>
 static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipStream_t st) {
     const bool extras = k.has_flat || k.out_sum_w;
     if (with_std) {
-        if (extras) return launch_one<NF, kUStd, TAB_PLAIN, true, false, true, 256>(k, st);
-        return launch_one<NF, kUStd, TAB_PLAIN, true, false, false, 256>(k, st);
+        if (extras) return launch_one<NF, kUStd, TAB_PLAIN, true, true, true, 256>(k, st);
+        if constexpr (NF == HM_TUNE_NF) {
+            if (c.prefetch) {
+                if (c.u == 1) return launch_one<NF, 1, TAB_PLAIN, true, true, false, 256>(k, st);
+                if (c.u == 2) return launch_one<NF, 2, TAB_PLAIN, true, true, false, 256>(k, st);
+                return launch_one<NF, 4, TAB_PLAIN, true, true, false, 256>(k, st);
+            }
+            if (c.u == 1) return launch_one<NF, 1, TAB_PLAIN, true, false, false, 256>(k, st);
+            if (c.u == 2) return launch_one<NF, 2, TAB_PLAIN, true, false, false, 256>(k, st);
+            return launch_one<NF, 4, TAB_PLAIN, true, false, false, 256>(k, st);
+        }
+        return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, 256>(k, st);
     }
     if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, false, true, 256>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
@@ -778,7 +793,7 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
 
 // elements per group of the configuration launch_fast_nf() will really use
 static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool extras) {
-    if (with_std) return kUStd * static_cast<int>(kSub);
+    if (with_std) return ((extras || n_frames != HM_TUNE_NF) ? kUStd : c.u) * static_cast<int>(kSub);
     if (extras || n_frames != HM_TUNE_NF) return kUVal * static_cast<int>(kSub);
     return c.u * static_cast<int>(kSub);
 }

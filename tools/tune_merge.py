@@ -44,32 +44,37 @@ def main():
     ap.add_argument("--random-dn", action="store_true", help="uniform random DNs instead of the radiance stack")
     ap.add_argument("--out", default="gpurun_out/tune_merge.json")
     ap.add_argument("--variants", default="")
+    ap.add_argument("--std", action="store_true", help="tune the std kernel (config 3 without corrections)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    frames, _, t = synthetic_stack_device(7, a.n, a.h, a.w, device=dev, uniform_dn=a.random_dn)
+    frames, stds, t = synthetic_stack_device(7, a.n, a.h, a.w, device=dev, uniform_dn=a.random_dn, with_std=a.std)
     icrf, diff = synthetic_icrf()
-    ref_plan = engine.plan_merge(frames, t, icrf, diff, variant=0)
+    ref_plan = engine.plan_merge(frames, t, icrf, diff, stds, variant=0)
     ref_plan.launch()
     torch.cuda.synchronize()
     ref = ref_plan.outputs["val"]
     nbytes = ref_plan.algorithmic_bytes
     if a.variants:
         variants = [int(v) for v in a.variants.split(",")]
+    elif a.std:
+        variants = [0] + [100 * pf + 10 * u for pf in (0, 1) for u in (1, 2, 4)]
     else:
         variants = [0] + [1000 * tab + 100 * pf + 10 * u + bc for tab in (0, 1, 5) for pf in (0, 1) for u in (2, 4, 8) for bc in (0, 1)]
     plans = []
     shared_out = ref_plan.outputs["val"]
     for v in variants:
         try:
-            plan = engine.plan_merge(frames, t, icrf, diff, variant=v)
+            plan = engine.plan_merge(frames, t, icrf, diff, stds, variant=v)
             plan.launch()
             torch.cuda.synchronize()
         except Exception as e:  # noqa
             print(f"variant {v}: {e}")
             continue
         ok = True if v // 1000 == 5 else bool(torch.equal(plan.outputs["val"], ref))
+        if a.std:
+            ok = ok and bool(torch.equal(plan.outputs["std"], ref_plan.outputs["std"]))
         plans.append((v, plan, ok, []))
-    for _ in range(6000):                      # pre-warm to the sustained clock
+    for _ in range(1200 if a.std else 6000):   # pre-warm to the sustained clock
         ref_plan.launch()
     torch.cuda.synchronize()
     for _ in range(a.rounds):
