@@ -72,6 +72,11 @@ _SIGNATURES = {
     "hm_binary_op": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                               C.POINTER(C.c_int64), C.c_void_p]),
     "hm_unary_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_apply_thresholds": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p]),
+    "hm_compute_difference": (C.c_int, [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p]),
+    "hm_interpolate": (C.c_int, [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_channel_statistics_workspace_bytes": (C.c_size_t, []),
+    "hm_channel_statistics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,207 @@
+// hm_stats.hip - the linearity-statistics row of SURVEY.md 8(f)-1 as HIP kernels (gfx950):
+//   hm_apply_thresholds      AbstractMeasurand.apply_thresholds          modules/measurand.py:375-428
+//   hm_compute_difference    AbstractMeasurand.compute_difference        modules/measurand.py:620-655
+//   hm_interpolate           AbstractMeasurand.interpolate               modules/measurand.py:657-681
+//   hm_channel_statistics    compute_dimension_statistics(axis = all but the last)   modules/measurand.py:318-350
+// Streaming, HBM-bound; the statistics are two deterministic reduction passes (per-workgroup partials by wave
+// shuffles + LDS, then one workgroup), NaNs ignored exactly as np.nansum / np.nanmean / np.nanstd do.
+#include "hm_common.h"
+#include <algorithm>
+
+namespace hm {
+
+struct ChanLimits { double lo[HM_MAX_CHANNELS]; double hi[HM_MAX_CHANNELS]; };
+
+__global__ __launch_bounds__(256) void k_thresholds(double* __restrict__ val, double* __restrict__ sd, const ChanLimits lim,
+                                                    int64_t n, int C) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        const double v = val[e];
+        if ((v < lim.lo[c]) | (v > lim.hi[c])) {           // measurand.py:418 (NaN compares false: stays NaN)
+            val[e] = nan;
+            if (sd) sd[e] = nan;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_difference(const double* __restrict__ x, const double* __restrict__ sx,
+                                                    const double* __restrict__ y, const double* __restrict__ sy, double mult,
+                                                    double* __restrict__ ad, double* __restrict__ ads,
+                                                    double* __restrict__ rd, double* __restrict__ rds, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const double xv = x[e], yv = y[e];
+        const double scale = mult * yv;                     // :634
+        const double a = xv - scale;                        // :635
+        ad[e] = a;
+        rd[e] = a / scale;                                  // :636
+        if (ads) {
+            const double xs = sx ? sx[e] : 0.0, ys = sy ? sy[e] : 0.0;
+            const double m1 = mult * ys;
+            ads[e] = sqrt(xs * xs + m1 * m1);               // :652
+            const double u1 = xs / (mult * yv);
+            const double u2 = (ys * xv) / (mult * (yv * yv));
+            rds[e] = sqrt(u1 * u1 + u2 * u2);               // :653
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_interpolate(const double* __restrict__ x0, const double* __restrict__ s0,
+                                                     const double* __restrict__ x1, const double* __restrict__ s1,
+                                                     double y0, double y1, double y, double* __restrict__ out,
+                                                     double* __restrict__ out_std, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const double a = y1 - y, b = y - y0, d = y1 - y0;
+    const double ca = (a / d) * (a / d), cb = (b / d) * (b / d);
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        out[e] = (x0[e] * a + x1[e] * b) / d;               // :665
+        if (out_std) out_std[e] = sqrt((s0 ? s0[e] : 0.0) * ca + (s1 ? s1[e] : 0.0) * cb);   // :679 as written
+    }
+}
+
+// ---- statistics -------------------------------------------------------------------------------
+constexpr int kStatBlocks = 1024;
+constexpr int kStatVals = 4;                                // per channel: 4 partial sums
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-level reduction of acc[C][4] -> partial[block][C][4]
+__device__ __forceinline__ void block_reduce_store(double (&acc)[HM_MAX_CHANNELS][kStatVals], double* partial) {
+    __shared__ double red[4][HM_MAX_CHANNELS * kStatVals];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < HM_MAX_CHANNELS; ++c)
+#pragma unroll
+        for (int k = 0; k < kStatVals; ++k) {
+            const double s = wave_sum_d(acc[c][k]);
+            if (lane == 0) red[wave][c * kStatVals + k] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < HM_MAX_CHANNELS * kStatVals)
+        partial[blockIdx.x * HM_MAX_CHANNELS * kStatVals + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// pass 1: weighted: [sum w, sum v*w, sum std (non-nan), count std non-nan]; unweighted: [sum v, count, 0, 0]
+// pass 2: weighted: [sum w (v-mean)^2, 0,0,0];                              unweighted: [sum (v-mean)^2, 0,0,0]
+template <int PASS>
+__global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
+                                               const double* __restrict__ mean /*pass 2*/, double* __restrict__ partial) {
+    double acc[HM_MAX_CHANNELS][kStatVals] = {};
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        const double v = val[e];
+        double t[kStatVals] = {0.0, 0.0, 0.0, 0.0};
+        if (sd) {
+            const double s = sd[e];
+            const double w = 1.0 / s;                                        // :342
+            if (PASS == 1) {
+                if (w == w) t[0] = w;                                       // nansum(weights)
+                const double vw = v * w;
+                if (vw == vw) t[1] = vw;                                    // nansum(values * weights)
+                if (s == s) { t[2] = s; t[3] = 1.0; }                       // nanmean(stds)
+            } else {
+                const double d = v - mean[c];
+                const double q = w * (d * d);                               // :345
+                if (q == q) t[0] = q;
+            }
+        } else {
+            if (PASS == 1) { if (v == v) { t[0] = v; t[1] = 1.0; } }
+            else { const double d = v - mean[c]; const double q = d * d; if (q == q) t[0] = q; }
+        }
+#pragma unroll
+        for (int k = 0; k < HM_MAX_CHANNELS; ++k)
+#pragma unroll
+            for (int j = 0; j < kStatVals; ++j) acc[k][j] += (k == c) ? t[j] : 0.0;
+    }
+    block_reduce_store(acc, partial);
+}
+
+// final: sums the partials in block order; stage 1 -> out[0..C) = mean, scratch keeps the denominators;
+//        stage 2 -> out[C..2C) = std, out[2C..3C) = error (nanmean of stds, weighted case only; NaN otherwise)
+template <int PASS>
+__global__ __launch_bounds__(64) void k_stats_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
+                                                    double* __restrict__ out, double* __restrict__ denom) {
+    const int t = threadIdx.x;
+    if (t >= C * kStatVals) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[b * HM_MAX_CHANNELS * kStatVals + t];
+    __shared__ double sums[HM_MAX_CHANNELS * kStatVals];
+    sums[t] = s;
+    __syncthreads();
+    if (t < C) {
+        const double* q = sums + t * kStatVals;
+        if (PASS == 1) {
+            if (weighted) { out[t] = q[1] / q[0]; denom[t] = q[0]; out[2 * C + t] = q[2] / q[3]; }
+            else { out[t] = q[0] / q[1]; denom[t] = q[1]; out[2 * C + t] = __longlong_as_double(0x7ff8000000000000ll); }
+        } else {
+            out[C + t] = sqrt(q[0] / denom[t]);
+        }
+    }
+}
+
+}  // namespace hm
+
+using namespace hm;
+
+extern "C" int hm_apply_thresholds(double* val, double* std, const double* lower, const double* upper,
+                                   int64_t n, int C, void* stream) {
+    if (n < 0 || C < 1 || C > HM_MAX_CHANNELS || !lower || !upper) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!val) return HM_EINVAL;
+    if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
+    ChanLimits lim{};
+    for (int c = 0; c < C; ++c) { lim.lo[c] = lower[c]; lim.hi[c] = upper[c]; }
+    hipLaunchKernelGGL(k_thresholds, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), val, std, lim, n, C);
+    return launch_status();
+}
+
+extern "C" int hm_compute_difference(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
+                                     double* out_abs, double* out_abs_std, double* out_rel, double* out_rel_std,
+                                     int64_t n, void* stream) {
+    if (n < 0) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!x || !y || !out_abs || !out_rel) return HM_EINVAL;
+    const bool with_std = sx || sy;
+    if (with_std != (out_abs_std != nullptr) || with_std != (out_rel_std != nullptr)) return HM_EINVAL;
+    hipLaunchKernelGGL(k_difference, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
+                       x, sx, y, sy, multiplier, out_abs, out_abs_std, out_rel, out_rel_std, n);
+    return launch_status();
+}
+
+extern "C" int hm_interpolate(const double* x0, const double* s0, const double* x1, const double* s1,
+                              double y0, double y1, double y, double* out, double* out_std, int64_t n, void* stream) {
+    if (n < 0) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!x0 || !x1 || !out || ((s0 || s1) != (out_std != nullptr))) return HM_EINVAL;
+    hipLaunchKernelGGL(k_interpolate, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
+                       x0, s0, x1, s1, y0, y1, y, out, out_std, n);
+    return launch_status();
+}
+
+extern "C" size_t hm_channel_statistics_workspace_bytes(void) {
+    return sizeof(double) * (kStatBlocks * HM_MAX_CHANNELS * kStatVals + HM_MAX_CHANNELS);
+}
+
+extern "C" int hm_channel_statistics(const double* val, const double* std, int64_t n, int C,
+                                     double* out /*3*C: mean, std, error*/, void* workspace, void* stream) {
+    if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !val || !out || !workspace) return HM_EINVAL;
+    if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
+    double* partial = static_cast<double*>(workspace);
+    double* denom = partial + kStatBlocks * HM_MAX_CHANNELS * kStatVals;
+    const int grid = static_cast<int>(std::min<int64_t>(kStatBlocks, (n + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    const int weighted = std ? 1 : 0;
+    hipLaunchKernelGGL(k_stats<1>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(nullptr), partial);
+    hipLaunchKernelGGL(k_stats_final<1>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_stats<2>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(out), partial);
+    hipLaunchKernelGGL(k_stats_final<2>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    return launch_status();
+}

@@ -479,3 +479,63 @@ def elementwise_unary(op: int, x: torch.Tensor, s):
         nat.check(nat.lib.hm_unary_op(op, x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_std), x.numel(),
                                       _stream(x.device)), "hm_unary_op")
     return out, out_std
+
+
+# ---------------------------------------------------------------------------------------------
+# linearity statistics
+# ---------------------------------------------------------------------------------------------
+def apply_thresholds_(val: torch.Tensor, std: Optional[torch.Tensor], lower: Sequence[float], upper: Sequence[float]) -> None:
+    """modules/measurand.py:375-428, in place on contiguous float64 device tensors (last axis = channels)."""
+    _require_cuda(val, "val")
+    Cc = val.shape[-1]
+    lo = (C.c_double * Cc)(*[float(x) for x in lower])
+    hi = (C.c_double * Cc)(*[float(x) for x in upper])
+    with torch.cuda.device(val.device):
+        nat.check(nat.lib.hm_apply_thresholds(val.data_ptr(), nat.ptr(std), lo, hi, val.numel(), Cc, _stream(val.device)),
+                  "hm_apply_thresholds")
+
+
+def compute_difference(x, sx, y, sy, multiplier: float):
+    """modules/measurand.py:620-655 -> (abs, abs_std, rel, rel_std)."""
+    _require_cuda(x, "x")
+    _require_cuda(y, "y")
+    x, y = x.contiguous(), y.contiguous()
+    sx = None if sx is None else sx.contiguous()
+    sy = None if sy is None else sy.contiguous()
+    with_std = sx is not None or sy is not None
+    ad, rd = torch.empty_like(x), torch.empty_like(x)
+    ads = torch.empty_like(x) if with_std else None
+    rds = torch.empty_like(x) if with_std else None
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.hm_compute_difference(x.data_ptr(), nat.ptr(sx), y.data_ptr(), nat.ptr(sy), float(multiplier),
+                                                ad.data_ptr(), nat.ptr(ads), rd.data_ptr(), nat.ptr(rds), x.numel(),
+                                                _stream(x.device)), "hm_compute_difference")
+    return ad, ads, rd, rds
+
+
+def interpolate(x0, s0, x1, s1, y0: float, y1: float, y: float):
+    """modules/measurand.py:657-681."""
+    _require_cuda(x0, "x0")
+    x0, x1 = x0.contiguous(), x1.contiguous()
+    s0 = None if s0 is None else s0.contiguous()
+    s1 = None if s1 is None else s1.contiguous()
+    out = torch.empty_like(x0)
+    out_std = torch.empty_like(x0) if (s0 is not None or s1 is not None) else None
+    with torch.cuda.device(x0.device):
+        nat.check(nat.lib.hm_interpolate(x0.data_ptr(), nat.ptr(s0), x1.data_ptr(), nat.ptr(s1), float(y0), float(y1), float(y),
+                                         out.data_ptr(), nat.ptr(out_std), x0.numel(), _stream(x0.device)), "hm_interpolate")
+    return out, out_std
+
+
+def channel_statistics(val: torch.Tensor, std: Optional[torch.Tensor]):
+    """modules/measurand.py:318-350 over every axis but the last -> dict(mean, std, error) of (C,) device tensors."""
+    _require_cuda(val, "val")
+    val = val.contiguous()
+    std = None if std is None else std.contiguous()
+    Cc = val.shape[-1]
+    out = torch.empty(3 * Cc, dtype=_F64, device=val.device)
+    ws = torch.empty(nat.lib.hm_channel_statistics_workspace_bytes() // 8, dtype=_F64, device=val.device)
+    with torch.cuda.device(val.device):
+        nat.check(nat.lib.hm_channel_statistics(val.data_ptr(), nat.ptr(std), val.numel(), Cc, out.data_ptr(), ws.data_ptr(),
+                                                _stream(val.device)), "hm_channel_statistics")
+    return {"mean": out[:Cc], "std": out[Cc:2 * Cc], "error": out[2 * Cc:] if std is not None else None}

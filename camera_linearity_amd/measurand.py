@@ -16,9 +16,10 @@ Extra: `val` may be a uint8 DN tensor (the reference accepts integer arrays in l
 measurand.py:505); `HipMeasurand.from_dn()` keeps an 8-bit frame as DNs in HBM (1 byte/element
 instead of 8) and materialises DN/255 (modules/image_set.py:223) only when `.val` is read.
 
-Rows "next" of SURVEY.md 8f (apply_thresholds, compute_dimension_statistics,
-compute_channel_histogram, compute_difference, interpolate, extract) are not hot-path kernels yet:
-they run as torch device ops on the same tensors so that the class surface is complete.
+Rows "next" of SURVEY.md 8f-1: apply_thresholds, compute_difference, interpolate and
+compute_dimension_statistics over the image axes run as HIP kernels (csrc/hm_stats.hip); exotic shapes
+(more than 4 channels, other reduction axes, broadcasting operands), extract and the host-side histogram
+use torch / NumPy on the same tensors so that the class surface is complete.
 """
 from __future__ import annotations
 
@@ -333,10 +334,18 @@ class HipMeasurand(AbstractMeasurand):
         upper = [None] * n if upper is None else upper
         if len(lower) != n or len(upper) != n:
             raise ValueError("The length of 'lower' and 'upper' must match the size of the independent axis.")
-        lo = torch.tensor([l if l is not None else -math.inf for l in lower], dtype=_F64, device=value.device)
-        hi = torch.tensor([u if u is not None else math.inf for u in upper], dtype=_F64, device=value.device)
+        lo_l = [l if l is not None else -math.inf for l in lower]
+        hi_l = [u if u is not None else math.inf for u in upper]
+        if value.is_cuda and n <= 4:
+            value = value.contiguous()
+            if self._std is not None and not self._std.is_contiguous():
+                self._std = self._std.contiguous()
+            _engine().apply_thresholds_(value, self._std, lo_l, hi_l)          # hm_apply_thresholds, in place
+            self.val = value
+            return
+        lo = torch.tensor(lo_l, dtype=_F64, device=value.device)
+        hi = torch.tensor(hi_l, dtype=_F64, device=value.device)
         mask = (value < lo) | (value > hi)
-        value = value.clone() if value is self._val else value
         value[mask] = math.nan
         self.val = value
         if self.std is not None:
@@ -345,6 +354,10 @@ class HipMeasurand(AbstractMeasurand):
     def compute_dimension_statistics(self, axis=None):
         """modules/measurand.py:318-350."""
         values = self._f64()
+        all_but_last = axis is not None and values.dim() >= 2 and \
+            sorted(a % values.dim() for a in ((axis,) if isinstance(axis, int) else tuple(axis))) == list(range(values.dim() - 1))
+        if values.is_cuda and all_but_last and values.shape[-1] <= 4:
+            return _engine().channel_statistics(values, self.std)                # hm_channel_statistics
         if self.std is None:
             mean = torch.nanmean(values, dim=axis) if axis is not None else torch.nanmean(values)
             cnt = (~torch.isnan(values)).sum(dim=axis) if axis is not None else (~torch.isnan(values)).sum()
@@ -382,6 +395,9 @@ class HipMeasurand(AbstractMeasurand):
         """modules/measurand.py:620-655."""
         cls = x.__class__
         xv, yv = x._f64(), y._f64()
+        if xv.is_cuda and xv.shape == yv.shape and (x.std is None or x.std.shape == xv.shape) and (y.std is None or y.std.shape == yv.shape):
+            ad, ads, rd, rds = _engine().compute_difference(xv, x.std, yv, y.std, multiplier)   # hm_compute_difference
+            return cls(ad, ads), cls(rd, rds)
         scale = multiplier * yv
         abs_diff = xv - scale
         rel_diff = abs_diff / scale
@@ -397,6 +413,9 @@ class HipMeasurand(AbstractMeasurand):
     def interpolate(x0: "HipMeasurand", x1: "HipMeasurand", y0: float, y1: float, y: float):
         """modules/measurand.py:657-681 (std formula as written)."""
         cls = x0.__class__
+        if x0._f64().is_cuda and x0.shape == x1.shape:
+            res, res_std = _engine().interpolate(x0._f64(), x0.std, x1._f64(), x1.std, y0, y1, y)   # hm_interpolate
+            return cls(res, res_std)
         res = (x0._f64() * (y1 - y) + x1._f64() * (y - y0)) / (y1 - y0)
         if x0.std is None and x1.std is None:
             return cls(res, None)

@@ -196,6 +196,28 @@ int hm_binary_op(int op, const double* x1, const double* s1, const double* x2, c
 int hm_unary_op(int op, const double* x, const double* s, double* out_val, double* out_std,
                 int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY.md 8(f)-1 - linearity statistics (ExposureSeries.process_linearity, modules/exposure_series.py:421-446)
+ *   hm_apply_thresholds     apply_thresholds (modules/measurand.py:375-428), in place: elements with
+ *                           val < lower[c] or val > upper[c] become NaN in val and std; pass -inf / +inf for "none".
+ *   hm_compute_difference   compute_difference (:620-655): abs = x - m*y, rel = abs / (m*y) and their std.
+ *   hm_interpolate          interpolate (:657-681), std formula as written.
+ *   hm_channel_statistics   compute_dimension_statistics (:318-350) over every axis but the last (the
+ *                           axis=(0,1) call of exposure_series.py:446): NaN-ignoring mean / std per channel,
+ *                           weighted by 1/std when std is given, plus error = nanmean(std). out is 3*C
+ *                           float64 on the device: [mean | std | error]; error is NaN without std.
+ * ------------------------------------------------------------------------------------------ */
+int hm_apply_thresholds(double* val, double* std /*nullable*/, const double* lower /*[host] C*/,
+                        const double* upper /*[host] C*/, int64_t n, int C, void* stream);
+int hm_compute_difference(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
+                          double* out_abs, double* out_abs_std, double* out_rel, double* out_rel_std,
+                          int64_t n, void* stream);
+int hm_interpolate(const double* x0, const double* s0, const double* x1, const double* s1,
+                   double y0, double y1, double y, double* out, double* out_std, int64_t n, void* stream);
+size_t hm_channel_statistics_workspace_bytes(void);
+int hm_channel_statistics(const double* val, const double* std /*nullable*/, int64_t n, int C,
+                          double* out, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
