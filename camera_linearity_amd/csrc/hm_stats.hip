@@ -147,6 +147,105 @@ __global__ __launch_bounds__(64) void k_stats_final(const double* __restrict__ p
     }
 }
 
+// ---- pair-fused linearity statistics ----------------------------------------------------------
+// ExposurePair.compute_difference + compute_stats(axis=(0,1)) (modules/exposure_series.py:33-54, called per pair
+// by process_linearity :443-446) without materialising the two difference images: each pass reads x, y (and
+// their stds) once and reduces both the absolute and the relative difference. out: 6*C doubles
+// [abs mean | abs std | abs error | rel mean | rel std | rel error].
+constexpr int kPairVals = 8;          // per channel: 4 sums for the absolute, 4 for the relative difference
+
+__device__ __forceinline__ void pair_terms(double xv, double xs, double yv, double ys, double mult, bool with_std,
+                                           double& a, double& as, double& r, double& rs) {
+    const double scale = mult * yv;                     // measurand.py:634
+    a = xv - scale;                                     // :635
+    r = a / scale;                                      // :636
+    if (with_std) {
+        const double m1 = mult * ys;
+        as = sqrt(xs * xs + m1 * m1);                   // :652
+        const double u1 = xs / (mult * yv);
+        const double u2 = (ys * xv) / (mult * (yv * yv));
+        rs = sqrt(u1 * u1 + u2 * u2);                   // :653
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x, const double* __restrict__ sx,
+                                                    const double* __restrict__ y, const double* __restrict__ sy, double mult,
+                                                    int64_t n, int C, const double* __restrict__ means /*pass 2: out[]*/,
+                                                    double* __restrict__ partial) {
+    __shared__ double red[4][HM_MAX_CHANNELS * kPairVals];
+    double acc[HM_MAX_CHANNELS][kPairVals] = {};
+    const bool with_std = sx || sy;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        double a, as = 0.0, r, rs = 0.0;
+        pair_terms(x[e], sx ? sx[e] : 0.0, y[e], sy ? sy[e] : 0.0, mult, with_std, a, as, r, rs);
+        double t[kPairVals] = {};
+        const double vv[2] = {a, r}, ss[2] = {as, rs};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double v = vv[h];
+            if (with_std) {
+                const double w = 1.0 / ss[h];
+                if (PASS == 1) {
+                    if (w == w) t[4 * h] = w;
+                    const double vw = v * w;
+                    if (vw == vw) t[4 * h + 1] = vw;
+                    if (ss[h] == ss[h]) { t[4 * h + 2] = ss[h]; t[4 * h + 3] = 1.0; }
+                } else {
+                    const double d = v - means[(h ? 3 * C : 0) + c];
+                    const double q = w * (d * d);
+                    if (q == q) t[4 * h] = q;
+                }
+            } else {
+                if (PASS == 1) { if (v == v) { t[4 * h] = v; t[4 * h + 1] = 1.0; } }
+                else { const double d = v - means[(h ? 3 * C : 0) + c]; const double q = d * d; if (q == q) t[4 * h] = q; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HM_MAX_CHANNELS; ++k)
+#pragma unroll
+            for (int j = 0; j < kPairVals; ++j) acc[k][j] += (k == c) ? t[j] : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < HM_MAX_CHANNELS; ++c)
+#pragma unroll
+        for (int k = 0; k < kPairVals; ++k) {
+            const double s = wave_sum_d(acc[c][k]);
+            if (lane == 0) red[wave][c * kPairVals + k] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < HM_MAX_CHANNELS * kPairVals)
+        partial[blockIdx.x * HM_MAX_CHANNELS * kPairVals + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int PASS>
+__global__ __launch_bounds__(64) void k_pair_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
+                                                   double* __restrict__ out, double* __restrict__ denom) {
+    const int t = threadIdx.x;
+    __shared__ double sums[HM_MAX_CHANNELS * kPairVals];
+    if (t < HM_MAX_CHANNELS * kPairVals) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[b * HM_MAX_CHANNELS * kPairVals + t];
+        sums[t] = s;
+    }
+    __syncthreads();
+    if (t < 2 * C) {
+        const int h = t / C, c = t % C;
+        const double* q = sums + c * kPairVals + 4 * h;
+        double* o = out + 3 * C * h;
+        if (PASS == 1) {
+            if (weighted) { o[c] = q[1] / q[0]; denom[t] = q[0]; o[2 * C + c] = q[2] / q[3]; }
+            else { o[c] = q[0] / q[1]; denom[t] = q[1]; o[2 * C + c] = __longlong_as_double(0x7ff8000000000000ll); }
+        } else {
+            o[C + c] = sqrt(q[0] / denom[t]);
+        }
+    }
+}
+
 }  // namespace hm
 
 using namespace hm;
@@ -203,5 +302,24 @@ extern "C" int hm_channel_statistics(const double* val, const double* std, int64
     hipLaunchKernelGGL(k_stats_final<1>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
     hipLaunchKernelGGL(k_stats<2>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(out), partial);
     hipLaunchKernelGGL(k_stats_final<2>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    return launch_status();
+}
+
+extern "C" size_t hm_pair_statistics_workspace_bytes(void) {
+    return sizeof(double) * (kStatBlocks * HM_MAX_CHANNELS * kPairVals + 2 * HM_MAX_CHANNELS);
+}
+
+extern "C" int hm_pair_statistics(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
+                                  int64_t n, int C, double* out /*6*C*/, void* workspace, void* stream) {
+    if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !x || !y || !out || !workspace) return HM_EINVAL;
+    double* partial = static_cast<double*>(workspace);
+    double* denom = partial + kStatBlocks * HM_MAX_CHANNELS * kPairVals;
+    const int grid = static_cast<int>(std::min<int64_t>(kStatBlocks, (n + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    const int weighted = (sx || sy) ? 1 : 0;
+    hipLaunchKernelGGL(k_pair_stats<1>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(nullptr), partial);
+    hipLaunchKernelGGL(k_pair_final<1>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_pair_stats<2>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(out), partial);
+    hipLaunchKernelGGL(k_pair_final<2>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
     return launch_status();
 }

@@ -539,3 +539,24 @@ def channel_statistics(val: torch.Tensor, std: Optional[torch.Tensor]):
         nat.check(nat.lib.hm_channel_statistics(val.data_ptr(), nat.ptr(std), val.numel(), Cc, out.data_ptr(), ws.data_ptr(),
                                                 _stream(val.device)), "hm_channel_statistics")
     return {"mean": out[:Cc], "std": out[Cc:2 * Cc], "error": out[2 * Cc:] if std is not None else None}
+
+
+def pair_statistics(x, sx, y, sy, multiplier: float):
+    """ExposurePair.compute_difference + compute_stats(axis=(0,1)) in one fused reduction (no difference images):
+    -> (absolute_stats, relative_stats), each dict(mean, std, error) of (C,) device tensors."""
+    _require_cuda(x, "x")
+    _require_cuda(y, "y")
+    if x.shape != y.shape:
+        raise ValueError("pair statistics need frames of equal shape")
+    x, y = x.contiguous(), y.contiguous()
+    sx = None if sx is None else sx.contiguous()
+    sy = None if sy is None else sy.contiguous()
+    Cc = x.shape[-1]
+    out = torch.empty(6 * Cc, dtype=_F64, device=x.device)
+    ws = torch.empty(nat.lib.hm_pair_statistics_workspace_bytes() // 8, dtype=_F64, device=x.device)
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.hm_pair_statistics(x.data_ptr(), nat.ptr(sx), y.data_ptr(), nat.ptr(sy), float(multiplier), x.numel(), Cc,
+                                             out.data_ptr(), ws.data_ptr(), _stream(x.device)), "hm_pair_statistics")
+    w = sx is not None or sy is not None
+    mk = lambda o: {"mean": out[o:o + Cc], "std": out[o + Cc:o + 2 * Cc], "error": out[o + 2 * Cc:o + 3 * Cc] if w else None}   # noqa: E731
+    return mk(0), mk(3 * Cc)

@@ -66,6 +66,15 @@ class ExposurePair(object):
             self.absolute_difference = None
             self.relative_difference = None
 
+    def compute_difference_stats(self):
+        """compute_difference() + compute_stats(axis=(0, 1), release_memory_after=True) in one fused HIP reduction
+        (hm_pair_statistics): the two difference images are never written to HBM."""
+        from . import engine
+        xs, ys = self.short_exposure.measurand, self.long_exposure.measurand
+        self.absolute_stats, self.relative_stats = engine.pair_statistics(xs._f64(), xs.std, ys._f64(), ys.std, self.exposure_ratio)
+        self.absolute_difference = None
+        self.relative_difference = None
+
     def process_linearity_distribution(self, bins: int, included_range=None, channels=None, use_std: Optional[bool] = False):
         return (self.absolute_difference.measurand.compute_channel_histogram(bins, included_range, channels, use_std),
                 self.relative_difference.measurand.compute_channel_histogram(bins, included_range, channels, use_std))
@@ -263,8 +272,12 @@ class ExposureSeries(object):
                 image_set.load_std_image()
             image_set.measurand.apply_thresholds(lower, upper)
         for pair in self.exposure_pairs:
-            pair.compute_difference()
-            pair.compute_stats(axis=(0, 1), release_memory_after=True)
+            v = pair.short_exposure.measurand.val
+            if v is not None and v.is_cuda and v.dim() == 3 and v.shape[-1] <= 4 and pair.long_exposure.measurand.shape == tuple(v.shape):
+                pair.compute_difference_stats()              # fused: no difference images in HBM
+            else:
+                pair.compute_difference()
+                pair.compute_stats(axis=(0, 1), release_memory_after=True)
 
     def collect_exposure_pair_stats(self, return_cupy: Optional[bool] = False):
         rel = {"ratios": [], "means": [], "stds": [], "errors": []}

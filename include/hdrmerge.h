@@ -214,6 +214,13 @@ int hm_compute_difference(const double* x, const double* sx, const double* y, co
                           int64_t n, void* stream);
 int hm_interpolate(const double* x0, const double* s0, const double* x1, const double* s1,
                    double y0, double y1, double y, double* out, double* out_std, int64_t n, void* stream);
+ /* hm_pair_statistics: ExposurePair.compute_difference + compute_stats(axis=(0,1)) fused
+ * (modules/exposure_series.py:33-54, the per-pair body of process_linearity :443-446): the statistics of
+ * the absolute and relative difference of two frames without writing the difference images.
+ * out is 6*C float64 on the device: [abs mean | abs std | abs error | rel mean | rel std | rel error]. */
+size_t hm_pair_statistics_workspace_bytes(void);
+int hm_pair_statistics(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
+                       int64_t n, int C, double* out, void* workspace, void* stream);
 size_t hm_channel_statistics_workspace_bytes(void);
 int hm_channel_statistics(const double* val, const double* std /*nullable*/, int64_t n, int C,
                           double* out, void* workspace, void* stream);
