@@ -505,6 +505,9 @@ __device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_
 #define HM_PIN(x) asm volatile("" : "+v"(x))
 
 constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
+#ifndef HM_FB
+#define HM_FB 4
+#endif
 
 template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool EXTRAS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
@@ -598,8 +601,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                             acc[j] = fma(wg, it, acc[j]);            // :388 numerator
                         }
                     }
-                    // bound the gathers in flight (4 frames = 8 ds_reads, 32 VGPRs) per scheduling bundle
-                    if ((i & 3) == 3 || i == NF - 1) {
+                    // bound the gathers in flight (HM_FB frames = 2*HM_FB ds_read_b128, 8*HM_FB VGPRs) per scheduling
+                    // bundle; HM_FB = 4 measured best (2: more VGPRs and 144 us; none: everything hoisted)
+                    if (((i % HM_FB) == HM_FB - 1 || i == NF - 1)) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) { HM_PIN(S[j]); HM_PIN(acc[j]); }
                         __builtin_amdgcn_sched_barrier(0);
@@ -706,12 +710,13 @@ int cu_count() {
 struct FastCfg { int tab, u, prefetch, block; };
 
 // Units per group (U sub-units of 128 elements) of the production configurations:
-constexpr int kUVal = 2;     // val-only: 256 contiguous bytes per frame per wave iteration (tune: 134.7 us vs 139.9 at U = 4)
+constexpr int kUVal = 2;     // val-only: 256 contiguous bytes per frame per wave iteration, next group prefetched
+                             // (132-136 us on every box seen; without prefetch 135-146 us depending on the box)
 constexpr int kUStd = 1;     // with std: one 128-element sub-unit per iteration + prefetch (tune: 684 us vs 753 at U = 2, no prefetch)
 
 static FastCfg default_cfg(bool with_std) {
     if (with_std) return FastCfg{TAB_PLAIN, kUStd, 1, 256};
-    return FastCfg{TAB_FUSED, kUVal, 0, 256};     // tools/tune_merge.py, tools/mergelab.hip, profiles/
+    return FastCfg{TAB_FUSED, kUVal, 1, 256};     // tools/tune_merge.py, tools/mergelab.hip, profiles/
 }
 
 static bool decode_variant(int variant, bool with_std, FastCfg& c) {
@@ -776,7 +781,7 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
         }
         return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, 256>(k, st);
     }
-    if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, false, true, 256>(k, st);
+    if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, true, true, 256>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
         if (c.prefetch) {
             if (c.u == 2) return launch_val_tab<NF, 2, true>(k, c, st);
@@ -787,7 +792,7 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
         if (c.u == 4) return launch_val_tab<NF, 4, false>(k, c, st);
         return launch_val_tab<NF, 8, false>(k, c, st);
     } else {
-        return launch_one<NF, kUVal, TAB_FUSED, false, false, false, 256>(k, st);
+        return launch_one<NF, kUVal, TAB_FUSED, false, true, false, 256>(k, st);
     }
 }
 
