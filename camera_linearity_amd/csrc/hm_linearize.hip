@@ -10,29 +10,22 @@ namespace hm {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void st2(double* p, double x, double y) {
-    f64x2 v; v.x = x; v.y = y;
-    *reinterpret_cast<f64x2*>(p) = v;
-}
 
 // ---------------- u8 -> DN/255 ----------------
+// 2 elements per lane: one ushort load (128 contiguous bytes per wave instruction) and one 16-byte store
+// (1 KB contiguous per wave instruction) - store instructions must cover whole 128-byte lines.
 __global__ __launch_bounds__(256) void k_u8_to_unit(const uint8_t* __restrict__ dn, double* __restrict__ out, int64_t n) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    const int64_t units = n / 4;
-    const bool vec_ok = aligned_dev(dn, 4) && aligned_dev(out, 16);
+    const int64_t units = n / 2;
+    const bool vec_ok = aligned_dev(dn, 2) && aligned_dev(out, 16);
     for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < units; u += stride) {
-        uint32_t r;
-        if (vec_ok) r = *reinterpret_cast<const uint32_t*>(dn + 4 * u);
-        else r = dn[4 * u] | (dn[4 * u + 1] << 8) | (dn[4 * u + 2] << 16) | (static_cast<uint32_t>(dn[4 * u + 3]) << 24);
-        const double a = static_cast<double>(r & 255u) / 255.0, b = static_cast<double>((r >> 8) & 255u) / 255.0;
-        const double c = static_cast<double>((r >> 16) & 255u) / 255.0, d = static_cast<double>(r >> 24) / 255.0;
-        if (vec_ok) { st2(out + 4 * u, a, b); st2(out + 4 * u + 2, c, d); }
-        else { out[4 * u] = a; out[4 * u + 1] = b; out[4 * u + 2] = c; out[4 * u + 3] = d; }
+        const uint32_t r = vec_ok ? static_cast<uint32_t>(__builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(dn + 2 * u)))
+                                  : (dn[2 * u] | (static_cast<uint32_t>(dn[2 * u + 1]) << 8));
+        const double a = static_cast<double>(r & 255u) / 255.0, b = static_cast<double>(r >> 8) / 255.0;
+        if (vec_ok) { f64x2 v; v.x = a; v.y = b; __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(out + 2 * u)); }
+        else { out[2 * u] = a; out[2 * u + 1] = b; }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const int64_t e = units * 4 + threadIdx.x;
-        out[e] = static_cast<double>(dn[e]) / 255.0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) out[n - 1] = static_cast<double>(dn[n - 1]) / 255.0;
 }
 
 // ---------------- gaussian weight ----------------
@@ -50,14 +43,28 @@ __global__ __launch_bounds__(256) void k_weight_f64(const double* __restrict__ v
 __global__ __launch_bounds__(256) void k_weight_u8(const uint8_t* __restrict__ dn, const double* __restrict__ w_lut,
                                                    const double* __restrict__ dw_lut, double* __restrict__ w,
                                                    double* __restrict__ dw, int64_t n) {
-    __shared__ double t_w[256], t_dw[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) { t_w[i] = w_lut[i]; t_dw[i] = dw_lut ? dw_lut[i] : 0.0; }
+    __shared__ double2 t[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) t[i] = double2{w_lut[i], dw_lut ? dw_lut[i] : 0.0};
     __syncthreads();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const uint32_t k = dn[e];
-        if (w) w[e] = t_w[k];
-        if (dw) dw[e] = t_dw[k];
+    const int64_t units = n / 2;
+    const bool vec_ok = aligned_dev(dn, 2) && (!w || aligned_dev(w, 16)) && (!dw || aligned_dev(dw, 16));
+    for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < units; u += stride) {
+        const uint32_t r = vec_ok ? static_cast<uint32_t>(__builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(dn + 2 * u)))
+                                  : (dn[2 * u] | (static_cast<uint32_t>(dn[2 * u + 1]) << 8));
+        const double2 a = t[r & 255u], b = t[r >> 8];
+        if (vec_ok) {
+            if (w) { f64x2 v; v.x = a.x; v.y = b.x; __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(w + 2 * u)); }
+            if (dw) { f64x2 v; v.x = a.y; v.y = b.y; __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(dw + 2 * u)); }
+        } else {
+            if (w) { w[2 * u] = a.x; w[2 * u + 1] = b.x; }
+            if (dw) { dw[2 * u] = a.y; dw[2 * u + 1] = b.y; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        const double2 a = t[dn[n - 1]];
+        if (w) w[n - 1] = a.x;
+        if (dw) dw[n - 1] = a.y;
     }
 }
 
@@ -77,36 +84,32 @@ __global__ __launch_bounds__(256) void k_linearize(const void* __restrict__ in, 
     const bool per_ch = lut_stride > 1;
     if (!F64IN) {
         const uint8_t* dn = static_cast<const uint8_t*>(in);
-        const int64_t units = n / 4;
-        const bool vec_ok = aligned_dev(dn, 4) && aligned_dev(out_val, 16) && (!with_std || (aligned_dev(sd, 16) && aligned_dev(out_std, 16)));
+        const int64_t units = n / 2;
+        const bool vec_ok = aligned_dev(dn, 2) && aligned_dev(out_val, 16) && (!with_std || (aligned_dev(sd, 16) && aligned_dev(out_std, 16)));
         for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < units; u += stride) {
-            const int64_t e0 = 4 * u;
-            uint32_t r;
-            if (vec_ok) r = *reinterpret_cast<const uint32_t*>(dn + e0);
-            else r = dn[e0] | (dn[e0 + 1] << 8) | (dn[e0 + 2] << 16) | (static_cast<uint32_t>(dn[e0 + 3]) << 24);
-            int c = per_ch ? static_cast<int>(e0 % C) : 0;
-            double g[4], ds[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t k = (r >> (8 * j)) & 255u;
-                const double2 gd = t[k * lut_stride + c];
-                g[j] = gd.x; ds[j] = gd.y;
-                if (per_ch) { ++c; if (c == C) c = 0; }
-            }
+            const int64_t e0 = 2 * u;
+            const uint32_t r = vec_ok ? static_cast<uint32_t>(__builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(dn + e0)))
+                                      : (dn[e0] | (static_cast<uint32_t>(dn[e0 + 1]) << 8));
+            const int c0 = per_ch ? static_cast<int>(e0 % C) : 0;
+            const int c1 = per_ch ? (c0 + 1 == C ? 0 : c0 + 1) : 0;
+            const double2 g0 = t[(r & 255u) * lut_stride + c0], g1 = t[(r >> 8) * lut_stride + c1];
+            double s0 = 0.0, s1 = 0.0;
             if (with_std) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ds[j] = ds[j] * sd[e0 + j];                  // measurand.py:512
+                if (vec_ok) { const f64x2 sv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sd + e0)); s0 = sv.x; s1 = sv.y; }
+                else { s0 = sd[e0]; s1 = sd[e0 + 1]; }
+                s0 = g0.y * s0; s1 = g1.y * s1;                                          // measurand.py:512
             }
             if (vec_ok) {
-                st2(out_val + e0, g[0], g[1]); st2(out_val + e0 + 2, g[2], g[3]);
-                if (with_std) { st2(out_std + e0, ds[0], ds[1]); st2(out_std + e0 + 2, ds[2], ds[3]); }
+                f64x2 v; v.x = g0.x; v.y = g1.x;
+                __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(out_val + e0));
+                if (with_std) { f64x2 q; q.x = s0; q.y = s1; __builtin_nontemporal_store(q, reinterpret_cast<f64x2*>(out_std + e0)); }
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { out_val[e0 + j] = g[j]; if (with_std) out_std[e0 + j] = ds[j]; }
+                out_val[e0] = g0.x; out_val[e0 + 1] = g1.x;
+                if (with_std) { out_std[e0] = s0; out_std[e0 + 1] = s1; }
             }
         }
-        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-            const int64_t e = units * 4 + threadIdx.x;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+            const int64_t e = n - 1;
             const double2 gd = t[dn[e] * lut_stride + (per_ch ? static_cast<int>(e % C) : 0)];
             out_val[e] = gd.x;
             if (with_std) out_std[e] = gd.y * sd[e];
@@ -132,7 +135,7 @@ extern "C" int hm_u8_to_unit_f64(const uint8_t* dn, double* out, int64_t n, void
     if (n < 0 || (n > 0 && (!dn || !out))) return HM_EINVAL;
     if (n == 0) return HM_OK;
     if (!aligned(out, 8)) return HM_EALIGN;
-    hipLaunchKernelGGL(k_u8_to_unit, dim3(stream_grid((n + 3) / 4, 256, 8)), dim3(256), 0, as_stream(stream), dn, out, n);
+    hipLaunchKernelGGL(k_u8_to_unit, dim3(stream_grid((n + 1) / 2, 256, 8)), dim3(256), 0, as_stream(stream), dn, out, n);
     return launch_status();
 }
 
@@ -149,7 +152,7 @@ extern "C" int hm_gaussian_weight_u8(const uint8_t* dn, const double* w_lut, con
     if (n < 0 || (n > 0 && (!dn || !w_lut || (!w && !dw) || (dw && !dw_lut)))) return HM_EINVAL;
     if (n == 0) return HM_OK;
     if ((w && !aligned(w, 8)) || (dw && !aligned(dw, 8))) return HM_EALIGN;
-    hipLaunchKernelGGL(k_weight_u8, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), dn, w_lut, dw_lut, w, dw, n);
+    hipLaunchKernelGGL(k_weight_u8, dim3(stream_grid((n + 1) / 2, 256, 8)), dim3(256), 0, as_stream(stream), dn, w_lut, dw_lut, w, dw, n);
     return launch_status();
 }
 
@@ -161,7 +164,7 @@ static int linearize_common(bool f64in, const void* in, const double* sd, const 
     if (n == 0) return HM_OK;
     if (!aligned(out_val, 8) || (out_std && !aligned(out_std, 8)) || (sd && !aligned(sd, 8)) || (f64in && !aligned(in, 8)))
         return HM_EALIGN;
-    const unsigned grid = stream_grid(f64in ? n : (n + 3) / 4, 256, 8);
+    const unsigned grid = stream_grid(f64in ? n : (n + 1) / 2, 256, 8);
     if (f64in)
         hipLaunchKernelGGL(k_linearize<true>, dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff,
                            out_val, out_std, out_idx, n, C, lut_stride);

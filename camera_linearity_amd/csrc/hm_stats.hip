@@ -62,7 +62,13 @@ __global__ __launch_bounds__(256) void k_interpolate(const double* __restrict__ 
 }
 
 // ---- statistics -------------------------------------------------------------------------------
-constexpr int kStatBlocks = 1024;
+constexpr int kStatBlocks = 2040;                           // a multiple of 12: total threads divisible by C = 1..4
+
+static int stat_grid(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    g = ((g + 11) / 12) * 12;
+    return static_cast<int>(g < kStatBlocks ? g : kStatBlocks);
+}
 constexpr int kStatVals = 4;                                // per channel: 4 partial sums
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -90,52 +96,86 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[HM_MAX_CHANNELS
 
 // pass 1: weighted: [sum w, sum v*w, sum std (non-nan), count std non-nan]; unweighted: [sum v, count, 0, 0]
 // pass 2: weighted: [sum w (v-mean)^2, 0,0,0];                              unweighted: [sum (v-mean)^2, 0,0,0]
+// The launch uses a total thread count that is a multiple of C (grid rounded to a multiple of 12 workgroups),
+// so a thread's elements all have the same channel c_t = first_element % C and it keeps 4 running sums, not 4*C.
 template <int PASS>
 __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
                                                const double* __restrict__ mean /*pass 2*/, double* __restrict__ partial) {
-    double acc[HM_MAX_CHANNELS][kStatVals] = {};
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const int c = static_cast<int>(e % C);
-        const double v = val[e];
-        double t[kStatVals] = {0.0, 0.0, 0.0, 0.0};
-        if (sd) {
-            const double s = sd[e];
-            const double w = 1.0 / s;                                        // :342
-            if (PASS == 1) {
-                if (w == w) t[0] = w;                                       // nansum(weights)
-                const double vw = v * w;
-                if (vw == vw) t[1] = vw;                                    // nansum(values * weights)
-                if (s == s) { t[2] = s; t[3] = 1.0; }                       // nanmean(stds)
-            } else {
-                const double d = v - mean[c];
-                const double q = w * (d * d);                               // :345
-                if (q == q) t[0] = q;
-            }
-        } else {
-            if (PASS == 1) { if (v == v) { t[0] = v; t[1] = 1.0; } }
-            else { const double d = v - mean[c]; const double q = d * d; if (q == q) t[0] = q; }
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int ct = static_cast<int>(first % C);
+    const double mu = PASS == 2 ? mean[ct] : 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    constexpr int UN = 4;                                   // independent loads in flight per lane
+    for (int64_t e = first; e < n; e += UN * stride) {
+        double vv[UN], sv[UN];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t q = e + u * stride;
+            ok[u] = q < n;
+            vv[u] = ok[u] ? __builtin_nontemporal_load(val + q) : 0.0;
+            sv[u] = (ok[u] && sd) ? __builtin_nontemporal_load(sd + q) : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < HM_MAX_CHANNELS; ++k)
+        for (int u = 0; u < UN; ++u) {
+            if (!ok[u]) continue;
+            const double v = vv[u];
+            if (sd) {
+                const double s = sv[u];
+                const double w = 1.0 / s;                                    // :342
+                if (PASS == 1) {
+                    if (w == w) t0 += w;                                    // nansum(weights)
+                    const double vw = v * w;
+                    if (vw == vw) t1 += vw;                                 // nansum(values * weights)
+                    if (s == s) { t2 += s; t3 += 1.0; }                     // nanmean(stds)
+                } else {
+                    const double d = v - mu;
+                    const double q2 = w * (d * d);                          // :345
+                    if (q2 == q2) t0 += q2;
+                }
+            } else {
+                if (PASS == 1) { if (v == v) { t0 += v; t1 += 1.0; } }
+                else { const double d = v - mu; const double q2 = d * d; if (q2 == q2) t0 += q2; }
+            }
+        }
+    }
+    double acc[HM_MAX_CHANNELS][kStatVals];
 #pragma unroll
-            for (int j = 0; j < kStatVals; ++j) acc[k][j] += (k == c) ? t[j] : 0.0;
+    for (int k = 0; k < HM_MAX_CHANNELS; ++k) {
+        const bool me = k == ct;
+        acc[k][0] = me ? t0 : 0.0; acc[k][1] = me ? t1 : 0.0; acc[k][2] = me ? t2 : 0.0; acc[k][3] = me ? t3 : 0.0;
     }
     block_reduce_store(acc, partial);
+}
+
+// Sums `ncols` columns of partial[nblocks][ncols] with 256 threads: thread t adds rows t/ncols, t/ncols + R, ...
+// (R = 256/ncols row groups), then the R partial sums of a column are added in a fixed order -> deterministic.
+template <int NCOLS>
+__device__ __forceinline__ void column_sums(const double* __restrict__ partial, int nblocks, double* sums /*LDS [NCOLS]*/) {
+    __shared__ double part[256];
+    constexpr int R = 256 / NCOLS;
+    const int col = threadIdx.x % NCOLS, rg = threadIdx.x / NCOLS;
+    double s = 0.0;
+    for (int b = rg; b < nblocks; b += R) s += partial[b * NCOLS + col];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < NCOLS) {
+        double tot = 0.0;
+        for (int r = 0; r < R; ++r) tot += part[r * NCOLS + threadIdx.x];
+        sums[threadIdx.x] = tot;
+    }
+    __syncthreads();
 }
 
 // final: sums the partials in block order; stage 1 -> out[0..C) = mean, scratch keeps the denominators;
 //        stage 2 -> out[C..2C) = std, out[2C..3C) = error (nanmean of stds, weighted case only; NaN otherwise)
 template <int PASS>
-__global__ __launch_bounds__(64) void k_stats_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
-                                                    double* __restrict__ out, double* __restrict__ denom) {
+__global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
+                                                     double* __restrict__ out, double* __restrict__ denom) {
     const int t = threadIdx.x;
-    if (t >= C * kStatVals) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[b * HM_MAX_CHANNELS * kStatVals + t];
     __shared__ double sums[HM_MAX_CHANNELS * kStatVals];
-    sums[t] = s;
-    __syncthreads();
+    column_sums<HM_MAX_CHANNELS * kStatVals>(partial, nblocks, sums);
     if (t < C) {
         const double* q = sums + t * kStatVals;
         if (PASS == 1) {
@@ -174,46 +214,59 @@ __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x
                                                     int64_t n, int C, const double* __restrict__ means /*pass 2: out[]*/,
                                                     double* __restrict__ partial) {
     __shared__ double red[4][HM_MAX_CHANNELS * kPairVals];
-    double acc[HM_MAX_CHANNELS][kPairVals] = {};
     const bool with_std = sx || sy;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const int c = static_cast<int>(e % C);
-        double a, as = 0.0, r, rs = 0.0;
-        pair_terms(x[e], sx ? sx[e] : 0.0, y[e], sy ? sy[e] : 0.0, mult, with_std, a, as, r, rs);
-        double t[kPairVals] = {};
-        const double vv[2] = {a, r}, ss[2] = {as, rs};
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;       // a multiple of C (see k_stats)
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int ct = static_cast<int>(first % C);
+    const double mu[2] = {PASS == 2 ? means[ct] : 0.0, PASS == 2 ? means[3 * C + ct] : 0.0};
+    double t[kPairVals] = {};
+    constexpr int UN = 2;
+    for (int64_t e0 = first; e0 < n; e0 += UN * stride) {
+        double xv[UN], yv[UN], xs[UN], ys[UN];
+        bool ok[UN];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const double v = vv[h];
-            if (with_std) {
-                const double w = 1.0 / ss[h];
-                if (PASS == 1) {
-                    if (w == w) t[4 * h] = w;
-                    const double vw = v * w;
-                    if (vw == vw) t[4 * h + 1] = vw;
-                    if (ss[h] == ss[h]) { t[4 * h + 2] = ss[h]; t[4 * h + 3] = 1.0; }
-                } else {
-                    const double d = v - means[(h ? 3 * C : 0) + c];
-                    const double q = w * (d * d);
-                    if (q == q) t[4 * h] = q;
-                }
-            } else {
-                if (PASS == 1) { if (v == v) { t[4 * h] = v; t[4 * h + 1] = 1.0; } }
-                else { const double d = v - means[(h ? 3 * C : 0) + c]; const double q = d * d; if (q == q) t[4 * h] = q; }
-            }
+        for (int u = 0; u < UN; ++u) {
+            const int64_t q = e0 + u * stride;
+            ok[u] = q < n;
+            xv[u] = ok[u] ? __builtin_nontemporal_load(x + q) : 0.0;
+            yv[u] = ok[u] ? __builtin_nontemporal_load(y + q) : 1.0;
+            xs[u] = (ok[u] && sx) ? __builtin_nontemporal_load(sx + q) : 0.0;
+            ys[u] = (ok[u] && sy) ? __builtin_nontemporal_load(sy + q) : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < HM_MAX_CHANNELS; ++k)
+        for (int u = 0; u < UN; ++u) {
+            if (!ok[u]) continue;
+            double a, as = 0.0, r, rs = 0.0;
+            pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, a, as, r, rs);
+            const double vv[2] = {a, r}, ss[2] = {as, rs};
 #pragma unroll
-            for (int j = 0; j < kPairVals; ++j) acc[k][j] += (k == c) ? t[j] : 0.0;
+            for (int h = 0; h < 2; ++h) {
+                const double v = vv[h];
+                if (with_std) {
+                    const double w = 1.0 / ss[h];
+                    if (PASS == 1) {
+                        if (w == w) t[4 * h] += w;
+                        const double vw = v * w;
+                        if (vw == vw) t[4 * h + 1] += vw;
+                        if (ss[h] == ss[h]) { t[4 * h + 2] += ss[h]; t[4 * h + 3] += 1.0; }
+                    } else {
+                        const double d = v - mu[h];
+                        const double q2 = w * (d * d);
+                        if (q2 == q2) t[4 * h] += q2;
+                    }
+                } else {
+                    if (PASS == 1) { if (v == v) { t[4 * h] += v; t[4 * h + 1] += 1.0; } }
+                    else { const double d = v - mu[h]; const double q2 = d * d; if (q2 == q2) t[4 * h] += q2; }
+                }
+            }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < HM_MAX_CHANNELS; ++c)
 #pragma unroll
         for (int k = 0; k < kPairVals; ++k) {
-            const double s = wave_sum_d(acc[c][k]);
+            const double s = wave_sum_d(c == ct ? t[k] : 0.0);
             if (lane == 0) red[wave][c * kPairVals + k] = s;
         }
     __syncthreads();
@@ -223,16 +276,11 @@ __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x
 }
 
 template <int PASS>
-__global__ __launch_bounds__(64) void k_pair_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
-                                                   double* __restrict__ out, double* __restrict__ denom) {
+__global__ __launch_bounds__(256) void k_pair_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
+                                                    double* __restrict__ out, double* __restrict__ denom) {
     const int t = threadIdx.x;
     __shared__ double sums[HM_MAX_CHANNELS * kPairVals];
-    if (t < HM_MAX_CHANNELS * kPairVals) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += partial[b * HM_MAX_CHANNELS * kPairVals + t];
-        sums[t] = s;
-    }
-    __syncthreads();
+    column_sums<HM_MAX_CHANNELS * kPairVals>(partial, nblocks, sums);
     if (t < 2 * C) {
         const int h = t / C, c = t % C;
         const double* q = sums + c * kPairVals + 4 * h;
@@ -295,13 +343,13 @@ extern "C" int hm_channel_statistics(const double* val, const double* std, int64
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
     double* partial = static_cast<double*>(workspace);
     double* denom = partial + kStatBlocks * HM_MAX_CHANNELS * kStatVals;
-    const int grid = static_cast<int>(std::min<int64_t>(kStatBlocks, (n + 255) / 256));
+    const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
     const int weighted = std ? 1 : 0;
     hipLaunchKernelGGL(k_stats<1>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(nullptr), partial);
-    hipLaunchKernelGGL(k_stats_final<1>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_stats_final<1>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
     hipLaunchKernelGGL(k_stats<2>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(out), partial);
-    hipLaunchKernelGGL(k_stats_final<2>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_stats_final<2>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
     return launch_status();
 }
 
@@ -314,12 +362,12 @@ extern "C" int hm_pair_statistics(const double* x, const double* sx, const doubl
     if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !x || !y || !out || !workspace) return HM_EINVAL;
     double* partial = static_cast<double*>(workspace);
     double* denom = partial + kStatBlocks * HM_MAX_CHANNELS * kPairVals;
-    const int grid = static_cast<int>(std::min<int64_t>(kStatBlocks, (n + 255) / 256));
+    const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
     const int weighted = (sx || sy) ? 1 : 0;
     hipLaunchKernelGGL(k_pair_stats<1>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(nullptr), partial);
-    hipLaunchKernelGGL(k_pair_final<1>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_pair_final<1>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
     hipLaunchKernelGGL(k_pair_stats<2>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(out), partial);
-    hipLaunchKernelGGL(k_pair_final<2>, dim3(1), dim3(64), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_pair_final<2>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
     return launch_status();
 }
