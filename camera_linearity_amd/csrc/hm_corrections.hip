@@ -8,45 +8,77 @@
 
 namespace hm {
 
-// median by counting, same selection rule as the fused kernel (hm_merge.hip)
-template <typename T>
-__device__ T median_full(const T* __restrict__ buf, int64_t H, int64_t W, int C, int64_t row, int64_t col, int c, int k) {
-    const int r = k / 2, m = (k * k) / 2;
-    T best = buf[(row * W + col) * C + c];
-    for (int py = -r; py <= r; ++py) {
-        const int64_t yy = reflect_index(row + py, H);
-        for (int px = -r; px <= r; ++px) {
-            const T v = buf[(yy * W + reflect_index(col + px, W)) * C + c];
-            int less = 0, leq = 0;
-            for (int qy = -r; qy <= r; ++qy) {
-                const int64_t y2 = reflect_index(row + qy, H);
-                for (int qx = -r; qx <= r; ++qx) {
-                    const T u = buf[(y2 * W + reflect_index(col + qx, W)) * C + c];
-                    less += (u < v);
-                    leq += (u <= v);
-                }
-            }
-            if (less <= m && m < leq) best = v;
-        }
-    }
-    return best;
-}
+// Streaming copy with the rare hot elements patched: every lane owns EL consecutive elements (16 bytes of x:
+// 16 uint8 or 2 float64), loads them and the matching map entries with vector loads, and a wave ballot finds the
+// lanes that hold hot elements; each hot element's k x k median is taken cooperatively by the whole wave
+// (wave_median, hm_common.h) and patched into the owning lane's registers before the single 16-byte store.
+template <typename T> struct Chunk;
+template <> struct Chunk<uint8_t> { static constexpr int EL = 16; };
+template <> struct Chunk<double>  { static constexpr int EL = 2; };
+
+typedef uint32_t cu32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_hot_filter(const T* __restrict__ x, const uint8_t* __restrict__ map_u8,
                                                     const double* __restrict__ map_f64, int min_dn, double thr, int k,
                                                     T* __restrict__ out, int64_t H, int64_t W, int C) {
+    constexpr int EL = Chunk<T>::EL;
     const int64_t n = H * W * C;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const bool hot = map_u8 ? (static_cast<int>(map_u8[e]) >= min_dn) : (map_f64[e] > thr);   // measurand.py:545
-        T v = x[e];
-        if (hot) {
-            const int64_t wc = W * C;
-            const int64_t row = e / wc, rem = e % wc;
-            v = median_full(x, H, W, C, row, rem / C, static_cast<int>(rem % C), k);
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (n + EL - 1) / EL;
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
+    const bool vec_x = aligned_dev(x, 16) && aligned_dev(out, 16);
+    for (int64_t cb = wave0 * 64; cb < n_chunks; cb += n_waves * 64) {          // wave-uniform trip count
+        const int64_t chunk = cb + lane;
+        const int64_t e0 = chunk * EL;
+        const int cnt = chunk < n_chunks ? static_cast<int>(n - e0 < EL ? n - e0 : EL) : 0;
+        T v[EL];
+        uint32_t hotbits = 0;
+        if (cnt == EL && vec_x) {
+            const cu32x4 r = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(x + e0));
+            __builtin_memcpy(v, &r, 16);
+        } else {
+            for (int j = 0; j < cnt; ++j) v[j] = x[e0 + j];
         }
-        out[e] = v;
+        if (map_u8 && cnt == EL && EL == 16 && aligned_dev(map_u8 + e0, 16)) {
+            const cu32x4 mr = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(map_u8 + e0));
+            const uint32_t w4[4] = {mr.x, mr.y, mr.z, mr.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                hotbits |= (static_cast<int>((w4[j >> 2] >> (8 * (j & 3))) & 255u) >= min_dn) ? (1u << j) : 0u;   // measurand.py:545
+        } else {
+            for (int j = 0; j < cnt; ++j) {
+                const bool hot = map_u8 ? (static_cast<int>(map_u8[e0 + j]) >= min_dn) : (map_f64[e0 + j] > thr);
+                hotbits |= hot ? (1u << j) : 0u;
+            }
+        }
+        unsigned long long pending = __ballot(hotbits != 0);
+        while (pending) {                                                        // rare
+            const int src = __ffsll(static_cast<long long>(pending)) - 1;
+            pending &= pending - 1;
+            uint32_t bits = __builtin_amdgcn_readlane(hotbits, src);
+            const int64_t base = (cb + src) * EL;
+            while (bits) {
+                const int j = __ffs(static_cast<int>(bits)) - 1;
+                bits &= bits - 1;
+                const int64_t e = base + j;
+                const int64_t wc = W * C;
+                const int64_t row = e / wc, rem = e % wc;
+                const T med = wave_median(x, H, W, C, 0, row, rem / C, static_cast<int>(rem % C), k);
+                if (lane == src) {
+#pragma unroll
+                    for (int q = 0; q < EL; ++q) v[q] = (q == j) ? med : v[q];
+                }
+            }
+        }
+        if (cnt == EL && vec_x) {
+            cu32x4 r;
+            __builtin_memcpy(&r, v, 16);
+            __builtin_nontemporal_store(r, reinterpret_cast<cu32x4*>(out + e0));
+        } else {
+            for (int j = 0; j < cnt; ++j) out[e0 + j] = v[j];
+        }
     }
 }
 
@@ -144,7 +176,7 @@ static int hot_filter_common(const T* x, const uint8_t* map_u8, const double* ma
     if (!x || !out || (!map_u8 && !map_f64) || x == out) return HM_EINVAL;
     if (k < 3 || k > 7 || (k % 2) == 0) return HM_EINVAL;
     if (sizeof(T) == 8 && (!aligned(x, 8) || !aligned(out, 8))) return HM_EALIGN;
-    hipLaunchKernelGGL(k_hot_filter<T>, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(k_hot_filter<T>, dim3(stream_grid((n + Chunk<T>::EL - 1) / Chunk<T>::EL, 256, 8)), dim3(256), 0, as_stream(stream),
                        x, map_u8, map_f64, min_dn, thr, k, out, H, W, C);
     return launch_status();
 }
