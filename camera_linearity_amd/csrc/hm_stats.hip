@@ -294,6 +294,95 @@ __global__ __launch_bounds__(256) void k_pair_final(const double* __restrict__ p
     }
 }
 
+// ---- per-channel histogram (compute_channel_histogram, modules/measurand.py:430-469) ----------------
+// np.histogram with `bins` equal-width bins on [lo, hi]: the bin of x is int((x - lo) * bins / (hi - lo)),
+// corrected against the actual edges (np.linspace(lo, hi, bins + 1), passed in by the caller) exactly as
+// numpy/lib/_histograms_impl.py does, the right edge inclusive. Non-finite values are skipped
+// (measurand.py:453); with weights, elements whose std is 0 are skipped and the weight is 1/std (:457-460).
+// Per-workgroup histograms in LDS (ds_add_f64), written as partials and column-summed: counts are exact,
+// weighted sums reproducible up to the order of the LDS atomics inside a workgroup.
+constexpr int kHistBlocks = 256;
+constexpr int kHistMaxBins = 2048;        // bins * C doubles of LDS per workgroup (<= 64 KB)
+
+__global__ __launch_bounds__(256) void k_hist(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
+                                              int chan_mask, const double* __restrict__ edges, int bins, double lo, double hi,
+                                              double* __restrict__ partial /*[grid][C*bins]*/) {
+    extern __shared__ double h[];
+    const int nb = C * bins;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) h[i] = 0.0;
+    __syncthreads();
+    const double norm = static_cast<double>(bins) / (hi - lo);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        if (!((chan_mask >> c) & 1)) continue;
+        const double x = val[e];
+        if (!(fabs(x) <= 1.79769313486231570e308)) continue;              // isfinite
+        double w = 1.0;
+        if (sd) {
+            const double s = sd[e];
+            if (s == 0.0) continue;                                         // :457
+            w = 1.0 / s;                                                    // :460
+        }
+        if (!(x >= lo && x <= hi)) continue;                                // outside the range: not counted
+        int idx = static_cast<int>((x - lo) * norm);
+        if (idx == bins) idx -= 1;
+        if (x < edges[idx]) idx -= 1;
+        else if (x >= edges[idx + 1] && idx != bins - 1) idx += 1;
+        atomicAdd(&h[c * bins + idx], w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) partial[static_cast<int64_t>(blockIdx.x) * nb + i] = h[i];
+}
+
+__global__ __launch_bounds__(256) void k_hist_final(const double* __restrict__ partial, int nblocks, int nb, double* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nblocks; ++b) s += partial[static_cast<int64_t>(b) * nb + i];
+        out[i] = s;
+    }
+}
+
+// per-channel min / max of the finite (and, with std, non-zero-std) values: the default range of np.histogram
+__global__ __launch_bounds__(256) void k_minmax(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
+                                                double* __restrict__ partial /*[grid][C][2]*/) {
+    __shared__ double red[4][HM_MAX_CHANNELS * 2];
+    double mn[HM_MAX_CHANNELS], mx[HM_MAX_CHANNELS];
+#pragma unroll
+    for (int k = 0; k < HM_MAX_CHANNELS; ++k) { mn[k] = 1.0 / 0.0; mx[k] = -1.0 / 0.0; }
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        const double x = val[e];
+        if (!(fabs(x) <= 1.79769313486231570e308)) continue;
+        if (sd && sd[e] == 0.0) continue;
+#pragma unroll
+        for (int k = 0; k < HM_MAX_CHANNELS; ++k) if (k == c) { mn[k] = fmin(mn[k], x); mx[k] = fmax(mx[k], x); }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < HM_MAX_CHANNELS; ++k) {
+        double a = mn[k], b = mx[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a = fmin(a, __shfl_down(a, off, 64)); b = fmax(b, __shfl_down(b, off, 64)); }
+        if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < HM_MAX_CHANNELS) {
+        const int k = threadIdx.x;
+        partial[(blockIdx.x * HM_MAX_CHANNELS + k) * 2] = fmin(fmin(red[0][2 * k], red[1][2 * k]), fmin(red[2][2 * k], red[3][2 * k]));
+        partial[(blockIdx.x * HM_MAX_CHANNELS + k) * 2 + 1] = fmax(fmax(red[0][2 * k + 1], red[1][2 * k + 1]), fmax(red[2][2 * k + 1], red[3][2 * k + 1]));
+    }
+}
+
+__global__ __launch_bounds__(64) void k_minmax_final(const double* __restrict__ partial, int nblocks, int C, double* __restrict__ out /*[C][2]*/) {
+    const int k = threadIdx.x;
+    if (k >= C) return;
+    double a = 1.0 / 0.0, b = -1.0 / 0.0;
+    for (int i = 0; i < nblocks; ++i) { a = fmin(a, partial[(i * HM_MAX_CHANNELS + k) * 2]); b = fmax(b, partial[(i * HM_MAX_CHANNELS + k) * 2 + 1]); }
+    out[2 * k] = a; out[2 * k + 1] = b;
+}
+
 }  // namespace hm
 
 using namespace hm;
@@ -369,5 +458,36 @@ extern "C" int hm_pair_statistics(const double* x, const double* sx, const doubl
     hipLaunchKernelGGL(k_pair_final<1>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
     hipLaunchKernelGGL(k_pair_stats<2>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(out), partial);
     hipLaunchKernelGGL(k_pair_final<2>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
+    return launch_status();
+}
+
+extern "C" size_t hm_histogram_workspace_bytes(int bins, int C) {
+    const size_t a = sizeof(double) * static_cast<size_t>(kHistBlocks) * static_cast<size_t>(bins) * static_cast<size_t>(C);
+    const size_t b = sizeof(double) * kHistBlocks * HM_MAX_CHANNELS * 2;
+    return a > b ? a : b;
+}
+
+extern "C" int hm_channel_minmax(const double* val, const double* std, int64_t n, int C, double* out /*2*C*/, void* workspace,
+                                 void* stream) {
+    if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !val || !out || !workspace) return HM_EINVAL;
+    const int grid = static_cast<int>(std::min<int64_t>(kHistBlocks, (n + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_minmax, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<double*>(workspace));
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, st, static_cast<const double*>(workspace), grid, C, out);
+    return launch_status();
+}
+
+extern "C" int hm_channel_histogram(const double* val, const double* std, int64_t n, int C, int channel_mask,
+                                    const double* edges /*device, bins + 1*/, int bins, double lo, double hi,
+                                    double* out /*C * bins*/, void* workspace, void* stream) {
+    if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || bins < 1 || !val || !edges || !out || !workspace || !(hi > lo)) return HM_EINVAL;
+    if (bins * C > kHistMaxBins * 4) return HM_EUNSUPPORTED;
+    const int nb = bins * C;
+    const int lds = nb * static_cast<int>(sizeof(double));
+    if (lds > 64 * 1024) return HM_EUNSUPPORTED;
+    const int grid = static_cast<int>(std::min<int64_t>(kHistBlocks, (n + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), lds, st, val, std, n, C, channel_mask, edges, bins, lo, hi, static_cast<double*>(workspace));
+    hipLaunchKernelGGL(k_hist_final, dim3((nb + 255) / 256), dim3(256), 0, st, static_cast<const double*>(workspace), grid, nb, out);
     return launch_status();
 }

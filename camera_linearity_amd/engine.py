@@ -560,3 +560,37 @@ def pair_statistics(x, sx, y, sy, multiplier: float):
     w = sx is not None or sy is not None
     mk = lambda o: {"mean": out[o:o + Cc], "std": out[o + Cc:o + 2 * Cc], "error": out[o + 2 * Cc:o + 3 * Cc] if w else None}   # noqa: E731
     return mk(0), mk(3 * Cc)
+
+
+def channel_histogram(val: torch.Tensor, std: Optional[torch.Tensor], bins: int, included_range, channels: Sequence[int]):
+    """modules/measurand.py:430-469 -> {c: (hist ndarray, bin_edges ndarray)} like np.histogram. A range of None is
+    evaluated per channel from the counted values (np.histogram's default), with one extra reduction."""
+    _require_cuda(val, "val")
+    val = val.contiguous()
+    std = None if std is None else std.contiguous()
+    Cc = val.shape[-1]
+    ws = torch.empty(max(1, nat.lib.hm_histogram_workspace_bytes(int(bins), Cc) // 8), dtype=_F64, device=val.device)
+    out = {}
+    with torch.cuda.device(val.device):
+        if included_range is None:
+            mm = torch.empty(2 * Cc, dtype=_F64, device=val.device)
+            nat.check(nat.lib.hm_channel_minmax(val.data_ptr(), nat.ptr(std), val.numel(), Cc, mm.data_ptr(), ws.data_ptr(),
+                                                _stream(val.device)), "hm_channel_minmax")
+            mmh = mm.cpu().numpy().reshape(Cc, 2)
+        groups = {}
+        for c in channels:
+            lo, hi = (float(mmh[c, 0]), float(mmh[c, 1])) if included_range is None else (float(included_range[0]), float(included_range[1]))
+            if lo == hi:                                   # np.histogram widens an empty range by +-0.5
+                lo, hi = lo - 0.5, hi + 0.5
+            groups.setdefault((lo, hi), []).append(c)
+        for (lo, hi), cs in groups.items():
+            edges = np.linspace(lo, hi, int(bins) + 1)
+            edges_d = torch.as_tensor(edges, device=val.device)
+            res = torch.empty(Cc * int(bins), dtype=_F64, device=val.device)
+            mask = sum(1 << c for c in cs)
+            nat.check(nat.lib.hm_channel_histogram(val.data_ptr(), nat.ptr(std), val.numel(), Cc, mask, edges_d.data_ptr(), int(bins), lo, hi,
+                                                   res.data_ptr(), ws.data_ptr(), _stream(val.device)), "hm_channel_histogram")
+            r = res.cpu().numpy().reshape(Cc, int(bins))
+            for c in cs:
+                out[c] = (r[c] if std is not None else r[c].astype(np.int64), edges)
+    return out

@@ -374,9 +374,13 @@ class HipMeasurand(AbstractMeasurand):
         return {"mean": mean, "std": sd, "error": err}
 
     def compute_channel_histogram(self, bins: int, included_range=None, channels=None, use_std: bool = False):
-        """modules/measurand.py:430-469 (histograms are evaluated on the host)."""
+        """modules/measurand.py:430-469: np.histogram per channel - hm_channel_histogram on the device (per-workgroup
+        LDS histograms), host NumPy only for more than 4 channels or more than 2048 bins."""
         if channels is None:
             channels = list(range(gs.NUM_OF_CHS))
+        vd = self._f64()
+        if vd.is_cuda and vd.shape[-1] <= 4 and bins * vd.shape[-1] <= 8192:
+            return _engine().channel_histogram(vd, self.std if use_std else None, bins, included_range, channels)
         v, s = self.to_numpy()
         out = {}
         for c in channels:

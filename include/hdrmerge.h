@@ -221,6 +221,15 @@ int hm_interpolate(const double* x0, const double* s0, const double* x1, const d
 size_t hm_pair_statistics_workspace_bytes(void);
 int hm_pair_statistics(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
                        int64_t n, int C, double* out, void* workspace, void* stream);
+/* hm_channel_histogram: compute_channel_histogram (modules/measurand.py:430-469) = np.histogram per channel on
+ * [lo, hi] with `bins` equal-width bins (edges = np.linspace(lo, hi, bins + 1) on the device), non-finite values
+ * skipped, optional weights 1/std with zero stds skipped. out is (C, bins) float64; channels not in
+ * channel_mask stay 0. hm_channel_minmax gives the default range (min / max of the counted values). */
+size_t hm_histogram_workspace_bytes(int bins, int C);
+int hm_channel_minmax(const double* val, const double* std /*nullable*/, int64_t n, int C, double* out /*2*C*/,
+                      void* workspace, void* stream);
+int hm_channel_histogram(const double* val, const double* std /*nullable*/, int64_t n, int C, int channel_mask,
+                         const double* edges, int bins, double lo, double hi, double* out, void* workspace, void* stream);
 size_t hm_channel_statistics_workspace_bytes(void);
 int hm_channel_statistics(const double* val, const double* std /*nullable*/, int64_t n, int C,
                           double* out, void* workspace, void* stream);

@@ -140,6 +140,32 @@ def test_linearize_property(M, c, h, w, seed, with_std):
     assert np.array_equal(M(v).lut_index().cpu().numpy(), idx)
 
 
+@pytest.mark.parametrize("use_std", [False, True])
+@pytest.mark.parametrize("rng_", [None, (0.1, 0.9)])
+def test_channel_histogram_matches_numpy(M, use_std, rng_):
+    """compute_channel_histogram (measurand.py:430-469) = np.histogram per channel; counts exact, weighted sums 1e-12."""
+    rng = np.random.default_rng(8)
+    v = rng.random((64, 48, 3))
+    v[3, 4, 0] = np.nan; v[5, 6, 1] = np.inf; v[0, 0, 2] = 0.9; v[1, 1, 2] = 0.1          # non-finite values and exact range edges
+    s = 0.05 + rng.random((64, 48, 3))
+    s[7, 7, 1] = 0.0
+    m = M(v, s)
+    got = m.compute_channel_histogram(32, rng_, [0, 2, 1], use_std)
+    for c in (0, 1, 2):
+        cv = v[..., c]
+        mask = np.isfinite(cv)
+        w = None
+        if use_std:
+            mask &= s[..., c] != 0
+            w = 1 / s[..., c][mask]
+        ref_h, ref_e = np.histogram(cv[mask], bins=32, range=rng_, weights=w)
+        np.testing.assert_allclose(got[c][1], ref_e, rtol=0, atol=0)
+        if use_std:
+            np.testing.assert_allclose(got[c][0], ref_h, rtol=1e-12)
+        else:
+            assert np.array_equal(got[c][0], ref_h)
+
+
 def _features(t):
     return {"illumination": "bf", "magnification": "5x", "exposure": float(t), "subject": "s"}
 
