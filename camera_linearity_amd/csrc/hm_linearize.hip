@@ -2,8 +2,8 @@
 //   hm_u8_to_unit_f64       modules/image_set.py:223        value = DN / 255
 //   hm_gaussian_weight_*    modules/measurand.py:606-618    w, dw
 //   hm_linearize_*          modules/measurand.py:471-541    ICRF LUT gather (+ ICRF_diff * std)
-// All are streaming kernels: 16-byte loads/stores per lane, LUTs staged in LDS, grid-stride over
-// "units" of 4 (uint8 input) or 2 (float64 input) consecutive elements.
+// All are streaming kernels: 2 elements per lane for uint8 input (ushort load, one 16-byte store that makes
+// every store instruction a contiguous 1 KB), LUTs staged in LDS, grid-stride loops.
 #include "hm_common.h"
 
 namespace hm {

@@ -98,7 +98,9 @@ int hm_linearize_f64(const double* v, const double* std, const double* icrf, con
  *   var    = sum_i ( ((dw_i g_i + w_i dg_i)/S - (dw_i w_i g_i)/S^2) dg_i/t_i )^2 (:389)
  *   std    = var ** (1/2)                                                       (:394)
  * with v_i the frame value BEFORE linearization, g_i = icrf[idx_i, c], dg_i = icrf_diff[idx_i, c] * std_i.
- * One launch reads every input byte once and writes every output byte once.
+ * One streaming launch reads every frame / std / flat byte once and writes every output byte once; when dark
+ * maps are given a second, stream-ordered launch reads each dark byte once and recomputes the (rare) elements
+ * that have a hot frame with the k x k medians substituted. Results do not depend on how the image is tiled.
  *
  * Tiling: a call produces image rows [row0, row0 + rows) of an H x W x C image.
  * Input frame / std / dark pointers address image row `buf_row0` (<= row0) and hold `buf_rows`
@@ -109,7 +111,7 @@ typedef struct hm_merge_args {
     uint32_t struct_size;         /* sizeof(hm_merge_args), for ABI evolution                       */
     int32_t  n_frames;            /* N, 1..HM_MAX_FRAMES, ascending exposure                        */
     int32_t  channels;            /* C, 1..HM_MAX_CHANNELS                                          */
-    int32_t  variant;             /* 0 = library default; >0 selects a tuning variant (bench only)  */
+    int32_t  variant;             /* 0 = library default; >0 selects a tuning variant (tools/tune_merge.py), <0 forces the generic kernel */
     int64_t  height;              /* H of the full image                                            */
     int64_t  width;               /* W                                                              */
     int64_t  row0, rows;          /* output rows of this call                                       */

@@ -262,6 +262,27 @@ def test_hot_pixel_fixup_batches(eng, n, k, f64):
     close(host(out["sum_w"]), ref["S"], 1e-13)
 
 
+@pytest.mark.parametrize("with_std", [False, True])
+def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std):
+    """variant < 0 forces merge_generic; it must reproduce merge_u8_fast bit for bit (shared operation sequence),
+    including flat field and sum-of-weights output."""
+    n, h, w = 7, 96, 130
+    frames, stds, t = orc.synthetic_stack(77, n, h, w, with_std=with_std)
+    icrf, diff = orc.synthetic_icrf()
+    rng = np.random.default_rng(3)
+    flat = dev(rng.integers(180, 230, size=(h, w, 3)).astype(np.uint8))
+    flat_std = dev(np.full((h, w, 3), 0.002))
+    fr = [dev(f) for f in frames]
+    sd = [dev(s) for s in stds] if with_std else None
+    kw = dict(flat=flat, ff_mean=[0.8, 0.81, 0.79], want_sum_w=True)
+    if with_std:
+        kw.update(flat_std=flat_std, ff_std_mean=[0.002] * 3)
+    a = eng.merge(fr, t, icrf, diff, sd, variant=0, **kw)
+    b = eng.merge(fr, t, icrf, diff, sd, variant=-1, **kw)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+
+
 def test_merge_argument_errors(eng):
     f = dev(np.zeros((4, 4, 3), np.uint8))
     icrf, diff = orc.synthetic_icrf()
