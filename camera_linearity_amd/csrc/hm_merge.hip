@@ -67,10 +67,9 @@ __device__ __forceinline__ void elem_to_pixel(const MergeK& a, int64_t e, int64_
 // operations, (val / F) * m (:602). The three variance terms (:586-596) each divide by F**2 or F**4 in the
 // reference; here 1/F**2 is formed once and multiplied (3 float64 divisions fewer per element; the std
 // moves by <= 2 ulp, its test tolerance is 1e-9).
-__device__ __forceinline__ void flat_field_math(double F, double sF, double m, double s, bool with_std,
-                                                double& val, double& sd) {
+__device__ __forceinline__ void flat_field_math(double F, double iF2 /* 1 / (F*F) */, double sF, double m, double s,
+                                                bool with_std, double& val, double& sd) {
     if (with_std) {
-        const double iF2 = 1.0 / (F * F);
         const double v2 = val * val;
         const double u_acq = ((sd * sd) * iF2) * (m * m);
         const double u_ff = ((v2 * (iF2 * iF2)) * (sF * sF)) * (m * m);
@@ -83,7 +82,7 @@ __device__ __forceinline__ void flat_field_math(double F, double sF, double m, d
 __device__ __forceinline__ void flat_field_apply(const MergeK& a, int64_t e, int c, bool with_std,
                                                  double& val, double& sd) {
     const double F = a.flat_u8 ? static_cast<double>(a.flat_u8[e]) / 255.0 : a.flat_f64[e];
-    flat_field_math(F, with_std ? a.flat_std[e] : 0.0, a.ff_mean[c], a.ff_std_mean[c], with_std, val, sd);
+    flat_field_math(F, with_std ? 1.0 / (F * F) : 1.0, with_std ? a.flat_std[e] : 0.0, a.ff_mean[c], a.ff_std_mean[c], with_std, val, sd);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,8 +461,8 @@ __device__ __forceinline__ void gather_val(const char* lds, uint32_t dn, uint32_
 // group are issued before the first gather; PREFETCH issues the next group's loads first.
 // Channel of element 2l + j of sub-unit s of group g: (g*U*128 + 128*s + 2l + j) % 3 = (2*(g*U + s + l) + j) % 3.
 //
-// EXTRAS = flat-field epilogue and/or sum-of-weights output compiled in (runtime-selected inside);
-// the plain instantiation has a branch-free epilogue.
+// FLAT / SUMW = flat-field epilogue / sum-of-weights output compiled in (separate instantiations: a runtime
+// branch around the flat-field loads cost config 3 ~100 us).
 
 // keeps an accumulator chain where the source puts it (hipcc otherwise sinks the second element's chain
 // below the first element's epilogue and keeps every gathered value live until then)
@@ -474,7 +473,7 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #define HM_FB 4
 #endif
 
-template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool EXTRAS, int BLOCK>
+template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int C = 3;
@@ -486,6 +485,14 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
         double2* t_gd = reinterpret_cast<double2*>(lds + 16 * 256);
         for (int i = threadIdx.x; i < 256; i += BLOCK) t_wdw[i] = double2{a.w_lut[i], a.dw_lut[i]};
         for (int i = threadIdx.x; i < 256 * C; i += BLOCK) t_gd[i] = double2{a.icrf[i], a.icrf_diff[i]};
+    }
+    // uint8 flat fields take only 256 values: {F = DN/255, 1/F**2} per DN in LDS saves two float64 divisions per element
+    double2* t_flat = reinterpret_cast<double2*>(lds + (STD ? kStdTabBytes : TabInfo<TAB>::bytes));
+    if constexpr (FLAT) {
+        for (int i = threadIdx.x; i < 256; i += BLOCK) {
+            const double F = static_cast<double>(i) / 255.0;
+            t_flat[i] = double2{F, 1.0 / (F * F)};
+        }
     }
     __syncthreads();
 
@@ -529,19 +536,20 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
             const uint32_t c1 = (c0 + 1u) % 3u;
             const uint32_t coffs[2] = {STD ? c0 * 16u : chan_off<TAB>(c0), STD ? c1 * 16u : chan_off<TAB>(c1)};
             double* ov = a.out_val + sbase;                                   // scalar bases
-            double* osw = EXTRAS && a.out_sum_w ? a.out_sum_w + sbase : nullptr;
+            double* osw = SUMW ? a.out_sum_w + sbase : nullptr;
 
             // flat-field operands of the lane's two elements (one ushort / 16-byte loads)
-            double F[2] = {1.0, 1.0}, sF[2] = {0.0, 0.0};
-            if constexpr (EXTRAS) {
-                if (a.has_flat) {
+            double F[2] = {1.0, 1.0}, sF[2] = {0.0, 0.0}, iF2[2] = {1.0, 1.0};
+            if constexpr (FLAT) {
+                {
                     if (a.flat_u8) {
                         const uint32_t f = ld_u16(a.flat_u8 + sbase + lane2);
-                        F[0] = static_cast<double>(f & 255u) / 255.0;
-                        F[1] = static_cast<double>(f >> 8) / 255.0;
+                        const double2 f0 = t_flat[f & 255u], f1 = t_flat[f >> 8];
+                        F[0] = f0.x; iF2[0] = f0.y; F[1] = f1.x; iF2[1] = f1.y;
                     } else {
                         const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(a.flat_f64 + sbase + lane2));
                         F[0] = f.x; F[1] = f.y;
+                        if (STD) { iF2[0] = 1.0 / (F[0] * F[0]); iF2[1] = 1.0 / (F[1] * F[1]); }
                     }
                     if (STD) {
                         const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(a.flat_std + sbase + lane2));
@@ -577,14 +585,12 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 double val[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) val[j] = acc[j] / S[j];
-                if constexpr (EXTRAS) {
-                    if (a.has_flat) {
-                        double dummy = 0.0;
-                        flat_field_math(F[0], 0.0, a.ff_mean[c0], 0.0, false, val[0], dummy);
-                        flat_field_math(F[1], 0.0, a.ff_mean[c1], 0.0, false, val[1], dummy);
-                    }
-                    if (osw) store2(osw + lane2, S[0], S[1]);
+                if constexpr (FLAT) {
+                    double dummy = 0.0;
+                    flat_field_math(F[0], iF2[0], 0.0, a.ff_mean[c0], 0.0, false, val[0], dummy);
+                    flat_field_math(F[1], iF2[1], 0.0, a.ff_mean[c1], 0.0, false, val[1], dummy);
                 }
+                if constexpr (SUMW) store2(osw + lane2, S[0], S[1]);
                 store2(ov + lane2, val[0], val[1]);
             } else {
                 const double2* t_wdw = reinterpret_cast<const double2*>(lds);
@@ -639,13 +645,11 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                     val[j] = acc[j] / S[j];
                     so[j] = sqrt(var[j]);                                                        // :394
                 }
-                if constexpr (EXTRAS) {
-                    if (a.has_flat) {
-                        flat_field_math(F[0], sF[0], a.ff_mean[c0], a.ff_std_mean[c0], true, val[0], so[0]);
-                        flat_field_math(F[1], sF[1], a.ff_mean[c1], a.ff_std_mean[c1], true, val[1], so[1]);
-                    }
-                    if (osw) store2(osw + lane2, S[0], S[1]);
+                if constexpr (FLAT) {
+                    flat_field_math(F[0], iF2[0], sF[0], a.ff_mean[c0], a.ff_std_mean[c0], true, val[0], so[0]);
+                    flat_field_math(F[1], iF2[1], sF[1], a.ff_mean[c1], a.ff_std_mean[c1], true, val[1], so[1]);
                 }
+                if constexpr (SUMW) store2(osw + lane2, S[0], S[1]);
                 store2(ov + lane2, val[0], val[1]);
                 store2(a.out_std + sbase + lane2, so[0], so[1]);
             }
@@ -698,10 +702,10 @@ static bool decode_variant(int variant, bool with_std, FastCfg& c) {
     return true;
 }
 
-template <int NF, int U, int TAB, bool STD, bool PF, bool EXTRAS, int BLOCK>
+template <int NF, int U, int TAB, bool STD, bool PF, bool FLAT, bool SUMW, int BLOCK>
 static int launch_one(const MergeK& k, hipStream_t st) {
-    constexpr int lds = STD ? kStdTabBytes : TabInfo<TAB>::bytes;
-    auto kernel = merge_u8_fast<NF, U, TAB, STD, PF, EXTRAS, BLOCK>;
+    constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + (FLAT ? 16 * 256 : 0);
+    auto kernel = merge_u8_fast<NF, U, TAB, STD, PF, FLAT, SUMW, BLOCK>;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
     const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
@@ -716,8 +720,8 @@ static int launch_one(const MergeK& k, hipStream_t st) {
 
 template <int NF, int U, int TAB, bool PF>
 static int launch_val_blk(const MergeK& k, const FastCfg& c, hipStream_t st) {
-    if (c.block == 256) return launch_one<NF, U, TAB, false, PF, false, 256>(k, st);
-    return launch_one<NF, U, TAB, false, PF, false, 1024>(k, st);
+    if (c.block == 256) return launch_one<NF, U, TAB, false, PF, false, false, 256>(k, st);
+    return launch_one<NF, U, TAB, false, PF, false, false, 1024>(k, st);
 }
 
 template <int NF, int U, bool PF>
@@ -729,24 +733,32 @@ static int launch_val_tab(const MergeK& k, const FastCfg& c, hipStream_t st) {
     }
 }
 
+template <int NF, bool STD, int U, int TAB>
+static int launch_extras(const MergeK& k, hipStream_t st) {
+    const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
+    if (flat && sumw) return launch_one<NF, U, TAB, STD, true, true, true, 256>(k, st);
+    if (flat) return launch_one<NF, U, TAB, STD, true, true, false, 256>(k, st);
+    return launch_one<NF, U, TAB, STD, true, false, true, 256>(k, st);
+}
+
 template <int NF>
 static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipStream_t st) {
     const bool extras = k.has_flat || k.out_sum_w;
     if (with_std) {
-        if (extras) return launch_one<NF, kUStd, TAB_PLAIN, true, true, true, 256>(k, st);
+        if (extras) return launch_extras<NF, true, kUStd, TAB_PLAIN>(k, st);
         if constexpr (NF == HM_TUNE_NF) {
             if (c.prefetch) {
-                if (c.u == 1) return launch_one<NF, 1, TAB_PLAIN, true, true, false, 256>(k, st);
-                if (c.u == 2) return launch_one<NF, 2, TAB_PLAIN, true, true, false, 256>(k, st);
-                return launch_one<NF, 4, TAB_PLAIN, true, true, false, 256>(k, st);
+                if (c.u == 1) return launch_one<NF, 1, TAB_PLAIN, true, true, false, false, 256>(k, st);
+                if (c.u == 2) return launch_one<NF, 2, TAB_PLAIN, true, true, false, false, 256>(k, st);
+                return launch_one<NF, 4, TAB_PLAIN, true, true, false, false, 256>(k, st);
             }
-            if (c.u == 1) return launch_one<NF, 1, TAB_PLAIN, true, false, false, 256>(k, st);
-            if (c.u == 2) return launch_one<NF, 2, TAB_PLAIN, true, false, false, 256>(k, st);
-            return launch_one<NF, 4, TAB_PLAIN, true, false, false, 256>(k, st);
+            if (c.u == 1) return launch_one<NF, 1, TAB_PLAIN, true, false, false, false, 256>(k, st);
+            if (c.u == 2) return launch_one<NF, 2, TAB_PLAIN, true, false, false, false, 256>(k, st);
+            return launch_one<NF, 4, TAB_PLAIN, true, false, false, false, 256>(k, st);
         }
-        return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, 256>(k, st);
+        return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256>(k, st);
     }
-    if (extras) return launch_one<NF, kUVal, TAB_FUSED, false, true, true, 256>(k, st);
+    if (extras) return launch_extras<NF, false, kUVal, TAB_FUSED>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
         if (c.prefetch) {
             if (c.u == 2) return launch_val_tab<NF, 2, true>(k, c, st);
@@ -757,7 +769,7 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
         if (c.u == 4) return launch_val_tab<NF, 4, false>(k, c, st);
         return launch_val_tab<NF, 8, false>(k, c, st);
     } else {
-        return launch_one<NF, kUVal, TAB_FUSED, false, true, false, 256>(k, st);
+        return launch_one<NF, kUVal, TAB_FUSED, false, true, false, false, 256>(k, st);
     }
 }
 
