@@ -822,6 +822,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     const int N = g->n_frames, C = g->channels;
     if (N < 1 || C < 1 || g->height < 1 || g->width < 1 || g->rows < 0) return HM_EINVAL;
     if (N > HM_MAX_FRAMES || C > HM_MAX_CHANNELS) return HM_EUNSUPPORTED;
+    if (g->rows == 0) return g->row0 >= 0 && g->row0 <= g->height ? HM_OK : HM_ESHAPE;   // empty tile: nothing to do
     const bool f64in = g->frames_f64 != nullptr;
     if (f64in == (g->frames_u8 != nullptr)) return HM_EINVAL;          // exactly one input kind
     if (!g->exposures || !g->icrf) return HM_EINVAL;
@@ -852,8 +853,6 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
         const int64_t need_hi = g->row0 + g->rows + r > g->height ? g->height : g->row0 + g->rows + r;
         if (g->buf_row0 > need_lo || g->buf_row0 + g->buf_rows < need_hi) return HM_ESHAPE;   // halo too small
     }
-    if (g->rows == 0) return HM_OK;
-
     MergeK k{};
     for (int i = 0; i < N; ++i) {
         const void* f = f64in ? static_cast<const void*>(g->frames_f64[i]) : static_cast<const void*>(g->frames_u8[i]);

@@ -283,6 +283,40 @@ def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std):
         assert torch.equal(a[key], b[key]), key
 
 
+@pytest.mark.parametrize("C", [1, 2, 4])
+@pytest.mark.parametrize("with_std", [False, True])
+def test_merge_other_channel_counts(eng, C, with_std):
+    """C != 3 takes the generic kernel (runtime channel count, HM_MAX_CHANNELS = 4)."""
+    n, h, w = 4, 9, 7
+    frames, stds, t = orc.synthetic_stack(300 + C, n, h, w, c=C, with_std=with_std)
+    icrf = np.stack([np.linspace(0, 1, 256) ** (1.5 + 0.2 * k) for k in range(C)], axis=1)
+    diff = orc.icrf_derivative(icrf)
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    out = eng.merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds] if with_std else None)
+    close(host(out["val"]), ref["val"], VAL_RTOL)
+    if with_std:
+        close(host(out["std"]), ref["std"], STD_RTOL)
+
+
+def test_merge_unaligned_tile_and_single_row(eng):
+    """Row tiles whose byte offset is odd (W*C odd) cannot use the 2-byte loads of the fast kernel: the generic kernel
+    takes over and the result is still bit-identical to the whole-image launch. Also rows == 0 and a 1 x 1 image."""
+    n, h, w = 3, 11, 5                      # W*C = 15 bytes per row: every other row starts at an odd address
+    frames, stds, t = orc.synthetic_stack(41, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    fr, sd = [dev(f) for f in frames], [dev(s) for s in stds]
+    whole = eng.merge(fr, t, icrf, diff, sd)
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    close(host(whole["val"]), ref["val"], VAL_RTOL)
+    for r0, r1 in ((1, 4), (3, 11), (0, 1), (10, 11)):
+        out = eng.merge(fr, t, icrf, diff, sd, height=h, row0=r0, rows=r1 - r0, buf_row0=0)
+        assert torch.equal(out["val"], whole["val"][r0:r1]) and torch.equal(out["std"], whole["std"][r0:r1])
+    empty = eng.merge(fr, t, icrf, diff, sd, height=h, row0=4, rows=0, buf_row0=0)
+    assert tuple(empty["val"].shape) == (0, w, 3)
+    one = eng.merge([dev(f[:1, :1]) for f in frames], t, icrf, diff)
+    close(host(one["val"]), orc.merge([f[:1, :1] for f in frames], t, icrf, diff)["val"], VAL_RTOL)
+
+
 def test_merge_argument_errors(eng):
     f = dev(np.zeros((4, 4, 3), np.uint8))
     icrf, diff = orc.synthetic_icrf()
