@@ -317,6 +317,39 @@ def test_merge_unaligned_tile_and_single_row(eng):
     close(host(one["val"]), orc.merge([f[:1, :1] for f in frames], t, icrf, diff)["val"], VAL_RTOL)
 
 
+def test_row_tile_sharding_helper_on_device(eng):
+    """parallel.merge_row_tile (what each rank of a row-sharded merge runs): the tiles of world sizes 1, 3 and 8,
+    computed one after the other on this GPU and concatenated, equal the whole-image merge bit for bit
+    (hot-pixel halo rows and flat-field rows included)."""
+    from camera_linearity_amd import parallel
+    rng = np.random.default_rng(12)
+    n, h, w = 5, 41, 18
+    frames, stds, t = orc.synthetic_stack(12, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    dark = rng.integers(0, 30, size=(h, w, 3)).astype(np.uint8)
+    dark[rng.random((h, w, 3)) < 0.02] = 250
+    flat = rng.integers(180, 230, size=(h, w, 3)).astype(np.uint8)
+    flat_std = np.full((h, w, 3), 0.002)
+    darks = [None, dark, dark, None, dark]
+    mins = [256, 40, 40, 256, 40]
+    kw = dict(stds_host=stds, darks_host=darks, dark_min=mins, median_k=3, flat_host=flat, flat_std_host=flat_std,
+              ff_mean=[0.8, 0.79, 0.81], ff_std_mean=[0.002] * 3)
+    _, _, whole_val, whole_std = parallel.merge_row_tile(frames, t, icrf, diff, rank=0, world_size=1, **kw)
+    ref = orc.merge(frames, t, icrf, diff, stds=stds, darks=[None if d is None else orc.unit_from_u8(d) for d in darks],
+                    dark_threshold=39.5 / 255, median_k=3, flat=orc.unit_from_u8(flat), flat_std=flat_std,
+                    ff_mean=np.array([0.8, 0.79, 0.81]), ff_std_mean=np.array([0.002] * 3))
+    close(whole_val, ref["val_ff"], VAL_RTOL)
+    close(whole_std, ref["std_ff"], STD_RTOL)
+    for world in (3, 8):
+        vals, sds = [], []
+        for r in range(world):
+            r0, r1, v, s = parallel.merge_row_tile(frames, t, icrf, diff, rank=r, world_size=world, **kw)
+            assert (r0, r1) == parallel.row_tile_bounds(h, world)[r] and v.shape[0] == r1 - r0
+            vals.append(v); sds.append(s)
+        assert np.array_equal(np.concatenate(vals), whole_val)
+        assert np.array_equal(np.concatenate(sds), whole_std)
+
+
 def test_merge_argument_errors(eng):
     f = dev(np.zeros((4, 4, 3), np.uint8))
     icrf, diff = orc.synthetic_icrf()
