@@ -405,9 +405,10 @@ constexpr int kStdTabBytes = 16 * 256 + 16 * 768;
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p));
 }
-__device__ __forceinline__ void store2(double* p, double x, double y) {
+// store two float64 at (scalar base) + (32-bit byte offset in a VGPR)
+__device__ __forceinline__ void store2(double* base, uint32_t byte_off, double x, double y) {
     f64x2 v; v.x = x; v.y = y;
-    __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(p));
+    __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(reinterpret_cast<char*>(base) + byte_off));
 }
 
 template <int TAB>
@@ -478,6 +479,28 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int C = 3;
     constexpr uint32_t GROUP = U * kSub;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane2 = lane * 2u;
+    const uint32_t lane16 = lane * 16u;          // byte offset of the lane's two float64 (scalar base + 32-bit VGPR offset addressing)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr uint32_t WPB = BLOCK / 64;
+    const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / GROUP);
+    const uint32_t gstride = gridDim.x * WPB;
+
+    uint32_t g = blockIdx.x * WPB + wave;                                   // wave-uniform
+    uint32_t raw[NF][U];
+    auto load_group = [&](uint32_t grp, uint32_t (&dst)[NF][U]) {
+        const int64_t off = a.in_off + static_cast<int64_t>(grp) * GROUP;   // scalar
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const uint8_t* p = static_cast<const uint8_t*>(a.frame[i]) + off;
+#pragma unroll
+            for (int s = 0; s < U; ++s) dst[i][s] = ld_u16(p + kSub * s + lane2);
+        }
+    };
+    // the first group's HBM loads are in flight while the workgroup builds its LDS tables
+    if (PREFETCH && g < n_groups) load_group(g, raw);
+
     if constexpr (!STD) {
         fill_val_tables<TAB>(lds, a);
     } else {
@@ -495,26 +518,6 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
         }
     }
     __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t lane2 = lane * 2u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr uint32_t WPB = BLOCK / 64;
-    const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / GROUP);
-    const uint32_t gstride = gridDim.x * WPB;
-
-    uint32_t g = blockIdx.x * WPB + wave;                                   // wave-uniform
-    uint32_t raw[NF][U];
-    auto load_group = [&](uint32_t grp, uint32_t (&dst)[NF][U]) {
-        const int64_t off = a.in_off + static_cast<int64_t>(grp) * GROUP;   // scalar
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const uint8_t* p = static_cast<const uint8_t*>(a.frame[i]) + off;
-#pragma unroll
-            for (int s = 0; s < U; ++s) dst[i][s] = ld_u16(p + kSub * s + lane2);
-        }
-    };
-    if (PREFETCH && g < n_groups) load_group(g, raw);
 
     for (; g < n_groups; g += gstride) {
         uint32_t cur[NF][U];
@@ -547,12 +550,12 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                         const double2 f0 = t_flat[f & 255u], f1 = t_flat[f >> 8];
                         F[0] = f0.x; iF2[0] = f0.y; F[1] = f1.x; iF2[1] = f1.y;
                     } else {
-                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(a.flat_f64 + sbase + lane2));
+                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_f64 + sbase) + lane16));
                         F[0] = f.x; F[1] = f.y;
                         if (STD) { iF2[0] = 1.0 / (F[0] * F[0]); iF2[1] = 1.0 / (F[1] * F[1]); }
                     }
                     if (STD) {
-                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(a.flat_std + sbase + lane2));
+                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_std + sbase) + lane16));
                         sF[0] = f.x; sF[1] = f.y;
                     }
                 }
@@ -590,20 +593,25 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                     flat_field_math(F[0], iF2[0], 0.0, a.ff_mean[c0], 0.0, false, val[0], dummy);
                     flat_field_math(F[1], iF2[1], 0.0, a.ff_mean[c1], 0.0, false, val[1], dummy);
                 }
-                if constexpr (SUMW) store2(osw + lane2, S[0], S[1]);
-                store2(ov + lane2, val[0], val[1]);
+                if constexpr (SUMW) store2(osw, lane16, S[0], S[1]);
+                store2(ov, lane16, val[0], val[1]);
             } else {
                 const double2* t_wdw = reinterpret_cast<const double2*>(lds);
                 const char* t_gd = lds + 16 * 256;
                 // pass 1: S = sum_i w_i
                 double S[2];
 #pragma unroll
-                for (int i = 0; i < NF; ++i)
+                for (int i = 0; i < NF; ++i) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const double w = t_wdw[j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8)].x;
                         if (i == 0) S[j] = w; else S[j] += w;
                     }
+                    if ((i & 3) == 3 && i != NF - 1) {      // at most 8 weight gathers in flight (large N: registers)
+                        HM_PIN(S[0]); HM_PIN(S[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 double invS[2], invS2[2], acc[2], var[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 for (int i = 0; i < NF; ++i) {
                     const double it = a.inv_t[i];
                     const double* sp = a.sd[i] + a.in_off + sbase;                               // scalar base
-                    const f64x2 sdv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sp + lane2));
+                    const f64x2 sdv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(sp) + lane16));
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const uint32_t dn = j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8);
@@ -649,9 +657,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                     flat_field_math(F[0], iF2[0], sF[0], a.ff_mean[c0], a.ff_std_mean[c0], true, val[0], so[0]);
                     flat_field_math(F[1], iF2[1], sF[1], a.ff_mean[c1], a.ff_std_mean[c1], true, val[1], so[1]);
                 }
-                if constexpr (SUMW) store2(osw + lane2, S[0], S[1]);
-                store2(ov + lane2, val[0], val[1]);
-                store2(a.out_std + sbase + lane2, so[0], so[1]);
+                if constexpr (SUMW) store2(osw, lane16, S[0], S[1]);
+                store2(ov, lane16, val[0], val[1]);
+                store2(a.out_std + sbase, lane16, so[0], so[1]);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep one sub-unit's gathers from piling onto the next one's
         }
