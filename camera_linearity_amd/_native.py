@@ -83,6 +83,14 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "hm_channel_statistics_workspace_bytes": (C.c_size_t, []),
     "hm_channel_statistics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hm_welford_update": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_int, C.c_void_p]),
+    "hm_welford_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_welford_algorithmic_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
+    "hm_linearity_energy_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "hm_linearity_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

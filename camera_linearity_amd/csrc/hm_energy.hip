@@ -1,0 +1,170 @@
+// hm_energy.hip - the ICRF-calibration energy function on the device (gfx950), for a whole population of
+// candidate ICRFs per launch: _energy_function + analyze_linearity,
+// modules/ICRF_calibration_exposure.py:66-145,148-201.
+//
+//   per candidate b (a 256-entry ICRF of one channel), frame pair i < j, pixel p:
+//       v_i = ICRF_b[dn[p, i]], NaN if v_i < ICRF_b[lower] or v_i > ICRF_b[upper]        (:96-97,:186-194)
+//       ratio = t_i / t_j                                                                  (:100)
+//       scaled = v_j * ratio                                                               (:111)
+//       d = v_i - scaled;  relative: d /= scaled;  a = |d|                                (:114-120)
+//       with std:  sigma = sqrt((s_i / scaled)^2 + ((v_i * s_j) / (ratio * v_j^2))^2)     (:127)
+//                  (absolute: sqrt(s_i^2 + (ratio * s_j)^2)                                :129)
+//                  w = 1 / sigma where a is finite and sigma != 0, else excluded          (:133-134)
+//                  result[i, j] = sum(a * w) / sum(w), NaN when sum(w) == 0               (general_functions.py:164-174)
+//       without:   result[i, j] = nanmean(a)                                              (:138)
+//   energy_b = nanmean over the pairs, +inf if that is NaN                                (:196-198)
+//
+// The stack is the reference's (X, Y, N) layout flattened to (P, N): a pixel's N samples are adjacent.
+// Launch geometry: grid = (pixel chunks, pairs, candidates): every workgroup reduces one pair of one candidate
+// over one pixel chunk, so even the reference's default few-hundred-pixel stacks fill the chip with
+// pairs x population workgroups (the reference evaluates one candidate at a time on the host). The sums are
+// formed in a fixed order (lane-strided, shuffle tree, chunk order), so results are reproducible run to run;
+// they differ from NumPy's pairwise summation in the last bits (tests: 1e-12 relative).
+#include "hm_common.h"
+
+namespace hm {
+
+struct EnergyK {
+    const uint8_t* dn;        // (P, N)
+    const double* sd;         // (P, N) or null
+    const double* icrf;       // (B, 256)
+    const uint8_t* valid;     // (B) or null: 0 = candidate rejected on the host, energy preset to +inf
+    double* partial;          // (B, pairs, chunks, 2)
+    int64_t P;
+    int32_t N, lower, upper, relative, chunks;
+    double t[HM_MAX_FRAMES];
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// pair index p (row-major upper triangle, np.triu_indices(N, 1) order) -> (i, j)
+__device__ __forceinline__ void pair_of(int p, int N, int& i, int& j) {
+    int row = 0, left = p;
+    while (left >= N - 1 - row) { left -= N - 1 - row; ++row; }
+    i = row; j = row + 1 + left;
+}
+
+template <bool STD>
+__global__ __launch_bounds__(256) void k_energy_partial(const EnergyK a) {
+    __shared__ double lut[256];
+    __shared__ double red[4][2];
+    const int b = blockIdx.z;
+    double* out = a.partial + ((static_cast<int64_t>(b) * gridDim.y + blockIdx.y) * a.chunks + blockIdx.x) * 2;
+    if (a.valid && !a.valid[b]) {                     // uniform per workgroup
+        if (threadIdx.x == 0) { out[0] = 0.0; out[1] = 0.0; }
+        return;
+    }
+    lut[threadIdx.x] = a.icrf[static_cast<int64_t>(b) * 256 + threadIdx.x];
+    __syncthreads();
+    int i, j;
+    pair_of(blockIdx.y, a.N, i, j);
+    const double lo = lut[a.lower], hi = lut[a.upper];
+    const double ratio = a.t[i] / a.t[j];
+    const int N = a.N;
+
+    double num = 0.0, den = 0.0;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < a.P; p += stride) {
+        const uint8_t* px = a.dn + p * N;
+        double vi = lut[px[i]], vj = lut[px[j]];
+        if (vi < lo || vi > hi) vi = __builtin_nan("");
+        if (vj < lo || vj > hi) vj = __builtin_nan("");
+        const double scaled = vj * ratio;
+        double d = vi - scaled;
+        if (a.relative) d = d / scaled;
+        const double ad = fabs(d);
+        if (STD) {
+            const double si = a.sd[p * N + i], sj = a.sd[p * N + j];
+            double sigma;
+            if (a.relative) {
+                const double u = si / scaled;
+                const double v = (vi * sj) / (ratio * (vj * vj));
+                sigma = sqrt(u * u + v * v);
+            } else {
+                const double v = ratio * sj;
+                sigma = sqrt(si * si + v * v);
+            }
+            const bool finite = isfinite(ad) && sigma != 0.0;
+            const double w = 1.0 / sigma;
+            if (finite && w == w) { num += ad * w; den += w; }
+        } else {
+            if (ad == ad) { num += ad; den += 1.0; }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double s0 = wave_sum(num), s1 = wave_sum(den);
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        out[1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+}
+
+// one wave per candidate: pair results (chunks summed in order) and the NaN-ignoring mean over pairs
+__global__ __launch_bounds__(64) void k_energy_final(const double* __restrict__ partial, const uint8_t* __restrict__ valid,
+                                                     int pairs, int chunks, double* __restrict__ out_pairs,
+                                                     double* __restrict__ out_energy) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const bool ok = !valid || valid[b];
+    double sum = 0.0, cnt = 0.0;
+    for (int p = lane; p < pairs; p += 64) {
+        const double* q = partial + (static_cast<int64_t>(b) * pairs + p) * chunks * 2;
+        double num = 0.0, den = 0.0;
+        for (int c = 0; c < chunks; ++c) { num += q[2 * c]; den += q[2 * c + 1]; }
+        const double r = ok ? num / den : __builtin_nan("");           // 0 / 0 = NaN: no contributing pixel
+        if (out_pairs) out_pairs[static_cast<int64_t>(b) * pairs + p] = r;
+        if (r == r) { sum += r; cnt += 1.0; }
+    }
+    sum = wave_sum(sum); cnt = wave_sum(cnt);
+    if (lane == 0) {
+        const double e = sum / cnt;
+        out_energy[b] = (ok && e == e) ? e : __builtin_inf();
+    }
+}
+
+static int energy_chunks(int64_t P) {
+    int64_t c = (P + 1023) / 1024;                  // >= 4 pixels per thread before splitting further
+    if (c < 1) c = 1;
+    return static_cast<int>(c > 64 ? 64 : c);
+}
+
+}  // namespace hm
+
+using namespace hm;
+
+extern "C" size_t hm_linearity_energy_workspace_bytes(int64_t n_pixels, int n_frames, int n_candidates) {
+    if (n_pixels < 0 || n_frames < 2 || n_candidates < 1) return 0;
+    const int64_t pairs = static_cast<int64_t>(n_frames) * (n_frames - 1) / 2;
+    return static_cast<size_t>(n_candidates) * pairs * energy_chunks(n_pixels) * 2 * sizeof(double);
+}
+
+extern "C" int hm_linearity_energy(const uint8_t* dn, const double* std, const double* exposures, const double* icrf,
+                                   const uint8_t* valid, int n_candidates, int lower, int upper, int use_relative,
+                                   int64_t n_pixels, int n_frames, double* out_pairs, double* out_energy,
+                                   void* workspace, void* stream) {
+    if (n_candidates < 0 || n_pixels < 0) return HM_EINVAL;
+    if (n_frames < 2 || n_frames > HM_MAX_FRAMES) return HM_ESHAPE;
+    if (lower < 0 || lower > 255 || upper < 0 || upper > 255) return HM_EINVAL;
+    if (n_candidates == 0) return HM_OK;
+    if (n_candidates > 65535) return HM_EUNSUPPORTED;
+    if (!dn || !exposures || !icrf || !out_energy || !workspace) return HM_EINVAL;
+    const int pairs = n_frames * (n_frames - 1) / 2;
+    EnergyK k{};
+    k.dn = dn; k.sd = std; k.icrf = icrf; k.valid = valid; k.partial = static_cast<double*>(workspace);
+    k.P = n_pixels; k.N = n_frames; k.lower = lower; k.upper = upper; k.relative = use_relative ? 1 : 0;
+    k.chunks = energy_chunks(n_pixels);
+    for (int i = 0; i < n_frames; ++i) k.t[i] = exposures[i];
+    const dim3 grid(k.chunks, pairs, n_candidates);
+    if (std) hipLaunchKernelGGL(k_energy_partial<true>, grid, dim3(256), 0, as_stream(stream), k);
+    else     hipLaunchKernelGGL(k_energy_partial<false>, grid, dim3(256), 0, as_stream(stream), k);
+    int rc = launch_status();
+    if (rc != HM_OK) return rc;
+    hipLaunchKernelGGL(k_energy_final, dim3(n_candidates), dim3(64), 0, as_stream(stream),
+                       static_cast<const double*>(workspace), valid, pairs, k.chunks, out_pairs, out_energy);
+    return launch_status();
+}

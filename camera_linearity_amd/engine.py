@@ -594,3 +594,90 @@ def channel_histogram(val: torch.Tensor, std: Optional[torch.Tensor], bins: int,
             for c in cs:
                 out[c] = (r[c] if std is not None else r[c].astype(np.int64), edges)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# upstream producer: Welford mean / M2 over video frames (modules/video_processing.py:161-219)
+# ------------------------------------------------------------------------------------------------
+def welford_update(frames: Sequence[torch.Tensor], count_before: int, mean: torch.Tensor, m2: Optional[torch.Tensor],
+                   icrf=None) -> int:
+    """Fold `frames` (uint8 (H, W, C) device tensors, in order) into the running float64 mean / m2 in place
+    (video_processing.py:199-208). Returns the new frame count. Frames are folded HM_MAX_FRAMES per launch."""
+    _require_cuda(mean, "mean")
+    if mean.dtype != _F64 or not mean.is_contiguous():
+        raise TypeError("mean must be a contiguous float64 tensor")
+    if m2 is not None and (m2.dtype != _F64 or not m2.is_contiguous() or m2.shape != mean.shape):
+        raise TypeError("m2 must be a contiguous float64 tensor shaped like mean")
+    dev = mean.device
+    Cc = mean.shape[-1]
+    lut = None if icrf is None else _dev_f64(icrf, dev)
+    if lut is not None and tuple(lut.shape) != (BITS, Cc):
+        raise ValueError(f"ICRF must be shaped ({BITS}, {Cc})")
+    count = int(count_before)
+    frames = list(frames)
+    for f in frames:
+        _require_cuda(f, "frame")
+        if f.dtype != torch.uint8 or f.shape != mean.shape:
+            raise ValueError("every frame must be a uint8 tensor shaped like mean")
+    with torch.cuda.device(dev):
+        for k0 in range(0, len(frames), nat.HM_MAX_FRAMES):
+            batch = [f.contiguous() for f in frames[k0:k0 + nat.HM_MAX_FRAMES]]
+            nat.check(nat.lib.hm_welford_update(_ptr_array(batch), len(batch), count, nat.ptr(lut), mean.data_ptr(), nat.ptr(m2),
+                                                mean.numel(), Cc, _stream(dev)), "hm_welford_update")
+            count += len(batch)
+    return count
+
+
+def welford_finalize(mean: torch.Tensor, m2: Optional[torch.Tensor], count: int):
+    """-> (mean frame uint8, std frame uint8 or None), video_processing.py:210-215."""
+    _require_cuda(mean, "mean")
+    out_mean = torch.empty(mean.shape, dtype=torch.uint8, device=mean.device)
+    out_std = None if m2 is None else torch.empty(mean.shape, dtype=torch.uint8, device=mean.device)
+    with torch.cuda.device(mean.device):
+        nat.check(nat.lib.hm_welford_finalize(mean.data_ptr(), nat.ptr(m2), int(count), out_mean.data_ptr(), nat.ptr(out_std),
+                                              mean.numel(), _stream(mean.device)), "hm_welford_finalize")
+    return out_mean, out_std
+
+
+# ------------------------------------------------------------------------------------------------
+# ICRF-calibration energy function (modules/ICRF_calibration_exposure.py:66-201), batched over candidates
+# ------------------------------------------------------------------------------------------------
+def linearity_energy(dn_stack: torch.Tensor, std_stack: Optional[torch.Tensor], exposures: Sequence[float], icrf_batch,
+                     lower: int, upper: int, valid=None, use_relative: bool = True, return_pairs: bool = False):
+    """Energy of every candidate ICRF row of `icrf_batch` ((B, 256) float64) on one channel's (X, Y, N) uint8 stack.
+    -> energies (B,) float64 device tensor [, pair results (B, N(N-1)/2)]."""
+    _require_cuda(dn_stack, "image_value_stack")
+    if dn_stack.dtype != torch.uint8:
+        raise TypeError("image_value_stack must be uint8 digital numbers")
+    if dn_stack.dim() != 3:
+        raise ValueError("image_stack must be a 3D array with shape (X, Y, N).")             # ICRF_calibration_exposure.py:82-83
+    dev = dn_stack.device
+    N = dn_stack.shape[2]
+    t = np.asarray(exposures, dtype=np.float64)
+    if t.ndim != 1 or t.size != N:
+        raise ValueError("exposure_values must be a 1D array matching the third dimension of image_stack.")   # :85-86
+    dn_stack = dn_stack.contiguous()
+    if std_stack is not None:
+        _require_cuda(std_stack, "image_std_stack")
+        if std_stack.shape != dn_stack.shape or std_stack.dtype != _F64:
+            raise ValueError("image_std_stack must be float64 and shaped like image_value_stack")
+        std_stack = std_stack.contiguous()
+    lut = _dev_f64(icrf_batch, dev)
+    if lut.dim() == 1:
+        lut = lut[None]
+    if lut.shape[1] != BITS:
+        raise ValueError(f"candidate ICRFs must have {BITS} entries")
+    lut = lut.contiguous()
+    B = lut.shape[0]
+    vd = None if valid is None else torch.as_tensor(np.asarray(valid, dtype=np.uint8), device=dev)
+    P = dn_stack.shape[0] * dn_stack.shape[1]
+    pairs = N * (N - 1) // 2
+    energy = torch.empty(B, dtype=_F64, device=dev)
+    out_pairs = torch.empty((B, pairs), dtype=_F64, device=dev) if return_pairs else None
+    ws = torch.empty(max(1, nat.lib.hm_linearity_energy_workspace_bytes(P, N, B) // 8), dtype=_F64, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib.hm_linearity_energy(dn_stack.data_ptr(), nat.ptr(std_stack), (C.c_double * N)(*t.tolist()), lut.data_ptr(),
+                                              nat.ptr(vd), B, int(lower), int(upper), int(bool(use_relative)), P, N,
+                                              nat.ptr(out_pairs), energy.data_ptr(), ws.data_ptr(), _stream(dev)),
+                  "hm_linearity_energy")
+    return (energy, out_pairs) if return_pairs else energy

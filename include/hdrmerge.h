@@ -236,6 +236,48 @@ size_t hm_channel_statistics_workspace_bytes(void);
 int hm_channel_statistics(const double* val, const double* std /*nullable*/, int64_t n, int C,
                           double* out, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Upstream producer: welford_algorithm, modules/video_processing.py:161-219.
+ *   hm_welford_update    folds n_frames uint8 frames (each n_elems = H*W*C, HWC) into the running float64
+ *                        mean / m2 (m2 nullable = use_std False), in frame order:
+ *                          f = icrf[dn, c] (:200-201; icrf (256, C) float64, nullable) or dn / 255 (:203);
+ *                          delta = f - mean; mean += delta / n; m2 += delta * (f - mean)   (:205-208)
+ *                        count_before = frames already folded (the caller keeps the count). mean / m2 must be
+ *                        zero-initialised by the caller before the first call (:181-184).
+ *   hm_welford_finalize  mean frame = around(mean * 255) as uint8 (:210-211); std frame =
+ *                        around(sqrt(m2 / (count - 1)) / sqrt(count)) as uint8 (:214-215, as written).
+ *                        out_std needs count >= 2 (HM_EINVAL otherwise).
+ *   hm_welford_algorithmic_bytes   n_elems * (n_frames + 16 or 32): each frame byte read once, the state
+ *                        read and written once per launch.
+ * ------------------------------------------------------------------------------------------ */
+int hm_welford_update(const void* const* frames /*[host] n_frames device ptrs*/, int n_frames, int64_t count_before,
+                      const double* icrf /*nullable*/, double* mean, double* m2 /*nullable*/,
+                      int64_t n_elems, int C, void* stream);
+int hm_welford_finalize(const double* mean, const double* m2 /*nullable*/, int64_t count,
+                        uint8_t* out_mean /*nullable*/, uint8_t* out_std /*nullable*/, int64_t n_elems, void* stream);
+int64_t hm_welford_algorithmic_bytes(int n_frames, int with_m2, int64_t n_elems);
+
+/* ------------------------------------------------------------------------------------------
+ * ICRF-calibration energy function: _energy_function + analyze_linearity,
+ * modules/ICRF_calibration_exposure.py:66-145,148-201, for n_candidates ICRFs of one channel per launch.
+ *   dn         (n_pixels, n_frames) uint8: the reference's (X, Y, N) channel stack (:257-277), frames ascending
+ *              in exposure; std (same shape, float64) nullable = use_std False
+ *   exposures  [host] n_frames exposure values (:282)
+ *   icrf       (n_candidates, 256) float64 on the device: each row already shifted to ICRF[255] = 1, ICRF[0] = 0
+ *              (:166-167); valid (n_candidates uint8, nullable): 0 marks a candidate the host rejected
+ *              (range / monotonicity tests :173-179): its energy is +inf and no pixel work is done
+ *   lower, upper   DN limits (:181-182): values outside [icrf[lower], icrf[upper]] are ignored (:96-97)
+ *   use_relative   analyze_linearity's flag (the energy function passes True, :192-193)
+ *   out_pairs  (n_candidates, n_frames (n_frames-1)/2) float64, nullable: the per-pair results in
+ *              np.triu_indices(N, 1) order (:141-143); out_energy (n_candidates): nanmean over the pairs,
+ *              +inf where that is NaN (:196-198)
+ * ------------------------------------------------------------------------------------------ */
+size_t hm_linearity_energy_workspace_bytes(int64_t n_pixels, int n_frames, int n_candidates);
+int hm_linearity_energy(const uint8_t* dn, const double* std /*nullable*/, const double* exposures /*[host]*/,
+                        const double* icrf, const uint8_t* valid /*nullable*/, int n_candidates,
+                        int lower, int upper, int use_relative, int64_t n_pixels, int n_frames,
+                        double* out_pairs /*nullable*/, double* out_energy, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

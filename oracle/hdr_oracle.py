@@ -351,6 +351,112 @@ def apply_thresholds(val, std, lower, upper):
 
 
 # --------------------------------------------------------------------------------------------
+# upstream producer: Welford mean / std frames (modules/video_processing.py:161-219)
+# --------------------------------------------------------------------------------------------
+def welford_state(frames, icrf=None, use_std=True, mean=None, m2=None, count=0):
+    """Running state after folding `frames` (uint8 (H, W, C) each): video_processing.py:199-208.
+    Deviation K: `if ICRF:` (:200) raises for an ndarray at HEAD; the intended test is `ICRF is not None`."""
+    frames = list(frames)
+    if mean is None:
+        mean = np.zeros(frames[0].shape, dtype=np.float64)                       # :181
+        m2 = np.zeros(frames[0].shape, dtype=np.float64) if use_std else None    # :184
+    C = mean.shape[-1]
+    for frame in frames:
+        count += 1                                                               # :197
+        if icrf is not None:
+            f = icrf[frame, np.arange(C)]                                        # :201
+        else:
+            f = (frame / MAX_DN).astype(np.float64)                              # :203
+        delta = f - mean                                                         # :205
+        mean = mean + delta / count                                              # :206
+        if use_std:
+            m2 = m2 + delta * (f - mean)                                         # :208
+    return mean, m2, count
+
+
+def welford_finalize(mean, m2, count):
+    """video_processing.py:210-215 as written (the std frame is not rescaled by MAX_DN)."""
+    mean_u8 = np.around(mean * MAX_DN).astype(np.uint8)
+    std_u8 = None
+    if m2 is not None:
+        std_u8 = np.around(np.sqrt(m2 / (count - 1)) / np.sqrt(count)).astype(np.uint8)
+    return mean_u8, std_u8
+
+
+def welford(frames, icrf=None, use_std=True):
+    mean, m2, count = welford_state(frames, icrf, use_std)
+    mean_u8, std_u8 = welford_finalize(mean, m2, count)
+    return {"mean": mean_u8, "std": std_u8}
+
+
+# --------------------------------------------------------------------------------------------
+# ICRF-calibration energy function (modules/ICRF_calibration_exposure.py:22-201)
+# --------------------------------------------------------------------------------------------
+def candidate_icrf(mean_icrf, pca_array, params, use_mean_icrf=True, bits: int = BITS):
+    """_inverse_camera_response_function (:22-45) followed by the shift of _energy_function (:166-167)."""
+    params = np.asarray(params, dtype=np.float64)
+    if use_mean_icrf:
+        icrf = mean_icrf + np.matmul(pca_array, params)                          # :41-43
+    else:
+        icrf = np.linspace(0, 1, bits) ** params[0] + np.matmul(pca_array, params[1:])   # :38-39
+    icrf = icrf + (1 - icrf[-1])                                                 # :166
+    icrf[0] = 0                                                                  # :167
+    return icrf
+
+
+def candidate_valid(icrf) -> bool:
+    """The rejection tests of _energy_function (:173-179): range, then strict monotonicity."""
+    if np.max(icrf) > 1 or np.min(icrf) < 0:
+        return False
+    return bool(np.all(icrf[1:] > icrf[:-1]))
+
+
+def analyze_linearity_pairs(values, stds, lower, upper, use_relative, exposures):
+    """analyze_linearity (:66-145) pair by pair: values / stds are (X, Y, N) float64 (stds may be None); returns the
+    N(N-1)/2 results in np.triu_indices(N, 1) order. Same per-element arithmetic as the (X, Y, N, N) broadcast."""
+    X, Y, N = values.shape
+    masked = np.where((values < lower) | (values > upper), np.nan, values)       # :96-97
+    out = []
+    with np.errstate(all="ignore"):
+        for i in range(N):
+            for j in range(i + 1, N):
+                ratio = exposures[i] / exposures[j]                              # :100
+                vi, vj = masked[:, :, i], masked[:, :, j]
+                scaled = vj * ratio                                              # :111
+                d = vi - scaled                                                  # :114
+                if use_relative:
+                    d = d / scaled                                               # :117
+                a = np.abs(d)                                                    # :120
+                if stds is not None:
+                    si, sj = stds[:, :, i], stds[:, :, j]
+                    if use_relative:
+                        sigma = np.sqrt((si / scaled) ** 2 + ((vi * sj) / (ratio * vj ** 2)) ** 2)   # :127
+                    else:
+                        sigma = np.sqrt(si ** 2 + (ratio * sj) ** 2)             # :129
+                    finite = np.logical_and(np.isfinite(a), sigma != 0)          # :133
+                    w = np.where(finite, 1 / sigma, np.nan)                      # :134
+                    ok = ~np.isnan(a) & ~np.isnan(w)                             # general_functions.py:164
+                    num = np.nansum(a * w * ok)                                  # :167
+                    den = np.nansum(ok * w)                                      # :170
+                    out.append(num / den if den != 0 else np.nan)                # :173-174
+                else:
+                    out.append(np.nanmean(a) if np.any(~np.isnan(a)) else np.nan)   # :138
+    return np.array(out)
+
+
+def energy_function(icrf, dn_stack, std_stack, lower, upper, exposures):
+    """_energy_function (:148-201) from the shifted candidate ICRF on: +inf for rejected candidates, the
+    LUT-mapped stack through analyze_linearity (relative), nanmean over pairs, NaN -> +inf."""
+    if not candidate_valid(icrf):
+        return np.inf
+    values = icrf[dn_stack]                                                      # :190
+    res = analyze_linearity_pairs(values, std_stack, icrf[lower], icrf[upper], True, np.asarray(exposures, dtype=np.float64))
+    with np.errstate(all="ignore"):
+        e = np.nanmean(res) if np.any(~np.isnan(res)) else np.nan                # :196
+    return float(np.inf if np.isnan(e) else e)                                   # :197-200
+
+
+# --------------------------------------------------------------------------------------------
 # synthetic workload of SURVEY.md section 8(d) (shared by tests and the bench's cpu_baseline leg)
 # --------------------------------------------------------------------------------------------
 def synthetic_stack(seed: int, n: int, h: int, w: int, c: int = 3, with_std: bool = False):

@@ -408,6 +408,76 @@ def case_operators():
     save("operators", **out)
 
 
+def case_welford():
+    """welford_algorithm (modules/video_processing.py:161-219) run as written on a seeded uint8 clip,
+    ICRF=None path (the ICRF path raises at HEAD: `if ICRF:` on an ndarray, deviation K)."""
+    import cv2
+    import general_functions as gf
+    import video_processing as vp
+    rng = np.random.default_rng(11)
+    h, w, n = 12, 20, 37
+    base = rng.integers(0, 256, (h, w, 3))
+    clip = np.clip(base[None] + np.around(rng.standard_normal((n, h, w, 3)) * 6), 0, 255).astype(np.uint8)
+
+    class Capture:                                     # stands in for cv.VideoCapture: only the two size queries
+        def __init__(self, path): pass
+        def get(self, prop): return {3: w, 4: h}[prop]
+    cv2.VideoCapture = Capture
+    cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT = 3, 4
+
+    def frames_of(path):
+        for f in clip:
+            yield f
+        yield None
+    gf.video_frame_generator = frames_of
+    with np.errstate(all="ignore"):
+        r_std = vp.welford_algorithm(pathlib.Path("clip.avi"), None, True)
+        r_mean = vp.welford_algorithm(pathlib.Path("clip.avi"), None, False)
+    assert r_mean["std"] is None and np.array_equal(r_mean["mean"], r_std["mean"])
+    save("welford", clip=clip, mean=r_std["mean"], std=r_std["std"])
+
+
+def case_energy():
+    """_energy_function / analyze_linearity (modules/ICRF_calibration_exposure.py:66-201) as written,
+    on a seeded (X, Y, N) uint8 channel stack, with and without std, for several PCA coefficient vectors
+    (including candidates the range / monotonicity tests reject)."""
+    import ICRF_calibration_exposure as ice
+    rng = np.random.default_rng(12)
+    X, Y, N = 14, 18, 5
+    t = 1e-3 * 2.0 ** np.arange(N)
+    rad = rng.random((X, Y)) * 4
+    k = 255 / (4 * t[N // 2])
+    true_resp = np.linspace(0, 1, 256) ** 1.8
+    lin = np.clip(rad[..., None] * t * k / 255, 0, 1)
+    dn = np.clip(np.around(np.interp(lin, true_resp, np.linspace(0, 1, 256)) * 255 + rng.standard_normal((X, Y, N))), 0, 255).astype(np.uint8)
+    sd = 0.004 * (1 + rng.random((X, Y, N)))
+    sd[0, 0, :] = 0.0                                   # zero std: sigma == 0 -> excluded (:133)
+    mean_icrf = np.linspace(0, 1, 256) ** 2.0
+    xs = np.linspace(0, 1, 256)
+    pca = np.stack([np.sin(np.pi * (m + 1) * xs) * 0.05 / (m + 1) for m in range(5)], axis=1)
+    params = np.concatenate([np.zeros((1, 5)), rng.uniform(-1, 1, (9, 5)), rng.uniform(-8, 8, (4, 5))])
+    lower, upper = 5, 250
+    e_plain, e_std, pairs_plain, pairs_std, icrfs = [], [], [], [], []
+    with np.errstate(all="ignore"):
+        for pv in params:
+            e_plain.append(ice._energy_function(pv.copy(), mean_icrf.copy(), pca, dn, None, lower, upper, True, t))
+            e_std.append(ice._energy_function(pv.copy(), mean_icrf.copy(), pca, dn, sd, lower, upper, True, t))
+            c = ice._inverse_camera_response_function(mean_icrf.copy(), pca, pv.copy(), True)
+            c += 1 - c[-1]
+            c[0] = 0
+            icrfs.append(c)
+            vals = c[dn]
+            pairs_plain.append(ice.analyze_linearity(vals, None, c[lower], c[upper], True, t))
+            pairs_std.append(ice.analyze_linearity(vals, sd, c[lower], c[upper], True, t))
+        vals = icrfs[0][dn]
+        abs_plain = ice.analyze_linearity(vals, None, icrfs[0][lower], icrfs[0][upper], False, t)
+        abs_std = ice.analyze_linearity(vals, sd, icrfs[0][lower], icrfs[0][upper], False, t)
+    save("energy", dn=dn, sd=sd, exposures=t, mean_icrf=mean_icrf, pca=pca, params=params,
+         lower=np.array(lower), upper=np.array(upper), icrfs=np.stack(icrfs),
+         energy_plain=np.array(e_plain), energy_std=np.array(e_std),
+         pairs_plain=np.stack(pairs_plain), pairs_std=np.stack(pairs_std), abs_plain=abs_plain, abs_std=abs_std)
+
+
 if __name__ == "__main__":
     case_identity()
     case_std()
@@ -416,3 +486,5 @@ if __name__ == "__main__":
     case_ramp()
     case_float()
     case_operators()
+    case_welford()
+    case_energy()

@@ -1,0 +1,218 @@
+"""GPU tests of the rows SURVEY.md 8(f) ranks after the merge: the Welford mean / std producer
+(modules/video_processing.py:161-219) and the ICRF-calibration energy function
+(modules/ICRF_calibration_exposure.py:66-201). Both go through the C ABI (hm_welford_*, hm_linearity_energy) and
+are checked against the oracle and the fixtures the reference itself produced."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import hdr_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from camera_linearity_amd import engine
+    return engine
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    return t if dtype is None else t.to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ Welford
+def test_welford_reference_fixture(eng, golden):
+    from camera_linearity_amd.video_processing import welford_algorithm
+    g = golden("welford")
+    r = welford_algorithm(g["clip"], None, True)
+    assert r["mean"].dtype == np.uint8 and np.array_equal(r["mean"], g["mean"])
+    assert np.array_equal(r["std"], g["std"])
+    r = welford_algorithm(list(g["clip"]) + [None], None, False, frames_per_launch=5)
+    assert r["std"] is None and np.array_equal(r["mean"], g["mean"])
+
+
+@pytest.mark.parametrize("shape,n,with_icrf,batch", [((12, 20, 3), 37, False, 16), ((7, 9, 3), 45, True, 32),
+                                                      ((5, 5, 1), 9, False, 4), ((3, 11, 4), 33, True, 7),
+                                                      ((1, 1, 3), 2, False, 1), ((16, 64, 3), 700, False, 32), ((16, 64, 3), 301, True, 32)])
+def test_welford_state_bit_exact(eng, shape, n, with_icrf, batch):
+    """The running float64 mean and M2 carry the oracle's bits (same op order, IEEE division), for every batch split."""
+    rng = np.random.default_rng(sum(shape) + n)
+    clip = rng.integers(0, 256, (n,) + shape, dtype=np.uint8)
+    icrf = np.linspace(0, 1, 256)[:, None] ** np.linspace(1.6, 2.4, shape[-1])[None, :] if with_icrf else None
+    mean_ref, m2_ref, cnt = orc.welford_state(list(clip), icrf, True)
+    mean = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    m2 = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    count = 0
+    frames = [dev(f) for f in clip]
+    for k0 in range(0, n, batch):
+        count = eng.welford_update(frames[k0:k0 + batch], count, mean, m2, icrf)
+    assert count == cnt
+    assert np.array_equal(mean.cpu().numpy(), mean_ref)
+    assert np.array_equal(m2.cpu().numpy(), m2_ref)
+    mu8, sd8 = eng.welford_finalize(mean, m2, count)
+    ref_mu8, ref_sd8 = orc.welford_finalize(mean_ref, m2_ref, cnt)
+    assert np.array_equal(mu8.cpu().numpy(), ref_mu8) and np.array_equal(sd8.cpu().numpy(), ref_sd8)
+    # mean only
+    mean2 = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    eng.welford_update(frames, 0, mean2, None, icrf)
+    assert np.array_equal(mean2.cpu().numpy(), mean_ref)
+
+
+def test_welford_unaligned_and_odd(eng):
+    """Odd element count and frames at odd byte offsets take the scalar path: same bits."""
+    rng = np.random.default_rng(5)
+    n, shape = 6, (3, 5, 3)                       # 45 elements (odd)
+    buf = torch.as_tensor(rng.integers(0, 256, n * 45 + 1, dtype=np.uint8), device="cuda")
+    frames = [buf[1 + k * 45: 1 + (k + 1) * 45].view(shape) for k in range(n)]       # odd offsets
+    clip = [f.cpu().numpy() for f in frames]
+    mean_ref, m2_ref, _ = orc.welford_state(clip, None, True)
+    mean = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    m2 = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    eng.welford_update(frames, 0, mean, m2)
+    assert np.array_equal(mean.cpu().numpy(), mean_ref) and np.array_equal(m2.cpu().numpy(), m2_ref)
+
+
+def test_welford_errors(eng):
+    from camera_linearity_amd.video_processing import welford_algorithm
+    with pytest.raises(ValueError):
+        welford_algorithm([], None, False)
+    with pytest.raises(ValueError):
+        welford_algorithm([np.zeros((2, 2, 3), np.uint8)], None, True)           # std needs two frames
+    with pytest.raises(TypeError):
+        welford_algorithm([np.zeros((2, 2, 3), np.float64)], None, False)
+    with pytest.raises(ValueError):
+        welford_algorithm([np.zeros((2, 2, 3), np.uint8), np.zeros((2, 3, 3), np.uint8)], None, False)
+
+
+def test_welford_large_constant_and_linearity(eng):
+    """Size-independent properties at a full-frame size: a constant clip has mean == the constant and M2 == 0; in
+    either frame order the running mean / M2 equal the two-pass values formed from the exact integer sum."""
+    H, W = 1024, 1536
+    const = torch.full((H, W, 3), 137, dtype=torch.uint8, device="cuda")
+    mean = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    m2 = torch.zeros_like(mean)
+    c = eng.welford_update([const] * 20, 0, mean, m2)
+    assert c == 20 and bool((mean == 137 / 255).all()) and bool((m2 == 0).all())
+    g = torch.Generator(device="cuda").manual_seed(3)
+    clip = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda", generator=g) for _ in range(12)]
+    exact = torch.stack(clip).to(torch.int64).sum(dim=0).double() / (12 * 255)         # exact integer sum
+    sq = (torch.stack(clip).double() / 255 - exact).pow(2).sum(dim=0)
+    for order in (clip, clip[::-1]):
+        mean.zero_(); m2.zero_()
+        c = eng.welford_update(order, 0, mean, m2)
+        assert float((mean - exact).abs().max()) < 1e-15
+        assert float((m2 - sq).abs().max()) < 1e-13
+
+
+# ------------------------------------------------------------------------------------------------ energy function
+def test_energy_reference_fixture(eng, golden):
+    from camera_linearity_amd import icrf_calibration as cal
+    g = golden("energy")
+    lo, up = int(g["lower"]), int(g["upper"])
+    dn, sd = dev(g["dn"]), dev(g["sd"])
+    for std, key, pkey in ((None, "energy_plain", "pairs_plain"), (sd, "energy_std", "pairs_std")):
+        # whole population in one launch
+        e = cal.energy_function_batch(g["params"], g["mean_icrf"], g["pca"], dn, std, lo, up, True, g["exposures"])
+        np.testing.assert_allclose(e, g[key], rtol=1e-12)
+        assert np.array_equal(np.isinf(e), np.isinf(g[key]))
+        # SciPy's vectorized calling convention (n_params, S)
+        e2 = cal._energy_function(g["params"].T, g["mean_icrf"], g["pca"], dn, std, lo, up, True, g["exposures"])
+        assert np.array_equal(e2, e)
+        # one candidate at a time: the reference's signature
+        for b in (0, 1, 3):
+            eb = cal._energy_function(g["params"][b], g["mean_icrf"], g["pca"], dn, std, lo, up, True, g["exposures"])
+            assert isinstance(eb, float) and eb == e[b]
+        icrfs, valid = cal.candidate_icrfs(g["params"], g["mean_icrf"], g["pca"])
+        assert np.array_equal(icrfs, g["icrfs"])
+        _, pairs = eng.linearity_energy(dn, std, g["exposures"], icrfs, lo, up, valid, True, return_pairs=True)
+        pairs = pairs.cpu().numpy()
+        np.testing.assert_allclose(pairs[valid], g[pkey][valid], rtol=1e-12, equal_nan=True)
+        assert np.isnan(pairs[~valid]).all()
+    # absolute mode of analyze_linearity
+    c = g["icrfs"][0]
+    np.testing.assert_allclose(cal.analyze_linearity(dn, None, c, lo, up, False, g["exposures"]).cpu().numpy(), g["abs_plain"],
+                               rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(cal.analyze_linearity(dn, sd, c, lo, up, False, g["exposures"]).cpu().numpy(), g["abs_std"],
+                               rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("X,Y,N,with_std", [(27, 27, 7, False), (27, 27, 7, True), (65, 129, 3, True), (9, 5, 12, False),
+                                            (300, 200, 4, True), (1, 1, 2, False)])
+def test_energy_vs_oracle(eng, X, Y, N, with_std):
+    rng = np.random.default_rng(X * 7 + N)
+    dn = rng.integers(0, 256, (X, Y, N), dtype=np.uint8)
+    sd = 0.004 * (1 + rng.random((X, Y, N))) if with_std else None
+    t = 1e-3 * 1.7 ** np.arange(N)
+    gammas = np.array([1.0, 1.5, 2.2, 3.0])
+    icrfs = np.linspace(0, 1, 256)[None, :] ** gammas[:, None]
+    icrfs[:, -1] = 1.0
+    e, pairs = eng.linearity_energy(dev(dn), None if sd is None else dev(sd), t, icrfs, 5, 250, None, True, return_pairs=True)
+    for b in range(len(gammas)):
+        ref_pairs = orc.analyze_linearity_pairs(icrfs[b][dn], sd, icrfs[b][5], icrfs[b][250], True, t)
+        np.testing.assert_allclose(pairs[b].cpu().numpy(), ref_pairs, rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(float(e[b]), orc.energy_function(icrfs[b], dn, sd, 5, 250, t), rtol=1e-12)
+
+
+def test_energy_all_masked_is_inf(eng):
+    dn = np.zeros((4, 4, 3), dtype=np.uint8)                        # every DN below `lower`
+    icrf = np.linspace(0, 1, 256)
+    e = eng.linearity_energy(dev(dn), None, [1.0, 2.0, 4.0], icrf[None], 5, 250)
+    assert np.isinf(float(e[0]))
+    assert np.isinf(orc.energy_function(icrf, dn, None, 5, 250, [1.0, 2.0, 4.0]))
+
+
+def test_energy_exact_linear_response_is_zero(eng):
+    """Size-independent property at a large size: a perfectly linear camera seen through the identity ICRF has zero
+    energy for the pairs whose samples stay inside the limits (here: all of them, by construction)."""
+    X, Y = 1024, 1024
+    base = torch.randint(10, 31, (X, Y), dtype=torch.uint8, device="cuda")
+    dn = torch.stack([base, base * 2, base * 4, base * 8], dim=-1).contiguous()       # DN proportional to exposure
+    icrf = np.arange(256) / 255.0
+    icrf[-1] = 1.0
+    e, pairs = eng.linearity_energy(dn, None, [1.0, 2.0, 4.0, 8.0], icrf[None], 5, 250, None, True, return_pairs=True)
+    assert float(pairs.abs().max()) < 1e-15 and float(e[0]) < 1e-15
+
+
+def test_energy_errors(eng):
+    dn = torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda")
+    icrf = np.linspace(0, 1, 256)[None]
+    with pytest.raises(ValueError):
+        eng.linearity_energy(dn[0], None, [1.0, 2.0, 4.0], icrf, 5, 250)            # not 3-D
+    with pytest.raises(ValueError):
+        eng.linearity_energy(dn, None, [1.0, 2.0], icrf, 5, 250)                    # exposures do not match N
+    with pytest.raises(TypeError):
+        eng.linearity_energy(dn.double(), None, [1.0, 2.0, 4.0], icrf, 5, 250)
+    with pytest.raises(ValueError):
+        eng.linearity_energy(dn[:, :, :1].contiguous(), None, [1.0], icrf, 5, 250)  # a single frame has no pairs
+
+
+def test_calibration_recovers_response(eng):
+    """End to end: differential evolution over PCA coefficients with the population evaluated per launch recovers a
+    synthetic camera response (energy drops by > 10x from the start point), in both solver modes."""
+    from camera_linearity_amd import icrf_calibration as cal
+    rng = np.random.default_rng(21)
+    X, Y, N = 40, 40, 6
+    t = 1e-3 * 2.0 ** np.arange(N)
+    xs = np.linspace(0, 1, 256)
+    pca = np.stack([np.sin(np.pi * (m + 1) * xs) / (m + 1) for m in range(3)], axis=1) * 0.1
+    mean_icrf = xs ** 2.0
+    true_params = np.array([0.6, -0.3, 0.2])
+    true_icrf, ok = cal.candidate_icrfs(true_params, mean_icrf, pca)
+    assert ok[0]
+    rad = rng.random((X, Y)) * 2.5 / t[-1]
+    lin = np.clip(rad[..., None] * t, 0, 1)
+    dn = np.clip(np.around(np.interp(lin, true_icrf[0], xs) * 255), 0, 255).astype(np.uint8)
+    stacks, stds, tt = cal.initialize_channel_image_stacks([dn[:, :, None, i].repeat(1, 2) for i in range(N)], t, None, 1)
+    assert stacks[0].shape == (X, Y, N) and np.array_equal(stacks[0].cpu().numpy(), dn)
+    e0 = cal._energy_function(np.zeros(3), mean_icrf, pca, stacks[0], None, 5, 250, True, tt)
+    e_true = cal._energy_function(true_params, mean_icrf, pca, stacks[0], None, 5, 250, True, tt)
+    assert e_true < e0 / 10
+    for vectorized, iters in ((True, 40), (False, 6)):
+        icrf, e, n_it = cal.solve_channel(mean_icrf, pca, stacks[0], None, tt, -1.0, 1.0, seed=7, max_iterations=iters,
+                                          vectorized=vectorized)
+        assert icrf.shape == (256,) and n_it <= iters
+        assert e < e0 / (10 if vectorized else 2), (vectorized, e, e0, e_true)

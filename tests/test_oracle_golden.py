@@ -157,3 +157,41 @@ def test_operators(golden):
     tv, ts = orc.apply_thresholds(a, sa, [0.4, None, 0.5], [1.0, 0.9, None])
     np.testing.assert_array_equal(tv, g["thr_val"])
     np.testing.assert_array_equal(ts, g["thr_std"])
+
+
+# ---- Welford mean / std frames (reference: video_processing.welford_algorithm as written) ----
+def test_welford_matches_reference(golden):
+    g = golden("welford")
+    r = orc.welford(list(g["clip"]), None, True)
+    assert np.array_equal(r["mean"], g["mean"])
+    assert np.array_equal(r["std"], g["std"])
+    assert orc.welford(list(g["clip"]), None, False)["std"] is None
+    # folding in two batches continues the same state bit for bit
+    m1, q1, c1 = orc.welford_state(list(g["clip"][:10]))
+    m2, q2, c2 = orc.welford_state(list(g["clip"][10:]), mean=m1, m2=q1, count=c1)
+    m, q, c = orc.welford_state(list(g["clip"]))
+    assert c2 == c and np.array_equal(m2, m) and np.array_equal(q2, q)
+
+
+# ---- ICRF-calibration energy function (reference: ICRF_calibration_exposure as written) ----
+def test_energy_function_matches_reference(golden):
+    g = golden("energy")
+    lo, up = int(g["lower"]), int(g["upper"])
+    n_valid = 0
+    for b, pv in enumerate(g["params"]):
+        c = orc.candidate_icrf(g["mean_icrf"], g["pca"], pv)
+        assert np.array_equal(c, g["icrfs"][b])
+        ok = orc.candidate_valid(c)
+        n_valid += ok
+        assert ok == np.isfinite(g["energy_plain"][b])
+        for sd, key, pkey in ((None, "energy_plain", "pairs_plain"), (g["sd"], "energy_std", "pairs_std")):
+            e = orc.energy_function(c, g["dn"], sd, lo, up, g["exposures"])
+            np.testing.assert_allclose(e, g[key][b], rtol=RTOL)
+            pairs = orc.analyze_linearity_pairs(c[g["dn"]], sd, c[lo], c[up], True, g["exposures"])
+            np.testing.assert_allclose(pairs, g[pkey][b], rtol=RTOL, equal_nan=True)
+    assert 0 < n_valid < len(g["params"])           # the fixture holds accepted and rejected candidates
+    c = g["icrfs"][0]
+    np.testing.assert_allclose(orc.analyze_linearity_pairs(c[g["dn"]], None, c[lo], c[up], False, g["exposures"]),
+                               g["abs_plain"], rtol=RTOL, equal_nan=True)
+    np.testing.assert_allclose(orc.analyze_linearity_pairs(c[g["dn"]], g["sd"], c[lo], c[up], False, g["exposures"]),
+                               g["abs_std"], rtol=RTOL, equal_nan=True)
