@@ -87,6 +87,8 @@ _SIGNATURES = {
                                     C.c_int64, C.c_int, C.c_void_p]),
     "hm_welford_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hm_welford_algorithmic_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
+    "hm_tiff_lzw_decode": (C.c_int64, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]),
+    "hm_tiff_packbits_decode": (C.c_int64, [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]),
     "hm_linearity_energy_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "hm_linearity_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,

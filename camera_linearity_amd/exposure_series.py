@@ -222,6 +222,9 @@ class ExposureSeries(object):
         from . import engine
         sets = self.input_image_sets
         if use_std is None:
+            for s in sets:                                  # the reference loads every frame's std image (:377)
+                if s.measurand.std is None and s.path is not None and s.measurand.shape is None:
+                    s.load_std_image()
             use_std = all(s.measurand.std is not None for s in sets)
         frames, stds, darks, mins = self._stack_inputs(list_of_dark_fields, dark_threshold, with_std=use_std)
         if ICRF_diff is None and use_std:

@@ -5,10 +5,10 @@ arguments and return values follow the reference; the arithmetic they trigger ru
 kernels behind HipMeasurand. File naming grammar (image_set.py:1-9, 542-568): descriptors separated
 by spaces - '<exposure>ms', 'bf'/'df', '<magnification>x', subject; ' STD' marks an uncertainty image.
 
-IO: the reference reads/writes TIFF through OpenCV, which is outside the hot path.
-Here `load_value_image` / `load_std_image` read with cv2 when it is importable and also accept
-`.npy` arrays; images can always be supplied in memory (`value=`, `std=`, `measurand=`). 8-bit
-images are kept as uint8 DNs in HBM.
+IO: the reference reads/writes TIFF through OpenCV. Here `load_value_image` /
+`load_std_image` / `save_64bit` / `save_8bit` go through `tiff_io` (cv.imread / cv.imwrite conventions
+without cv2: BGR arrays, RGB files, 8-bit and float64 samples) and also accept `.npy` arrays; images can
+always be supplied in memory (`value=`, `std=`, `measurand=`). 8-bit images are kept as uint8 DNs in HBM.
 
 Deviations: G - bad_pixel_filter / flat_field_correction return the new ImageSet as
 the reference does, and the merge loop uses the result; I - scale_to_exposure scales by
@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import settings as gs
+from . import tiff_io
 from .measurand import HipMeasurand
 from .measurand_factory import Measurand
 
@@ -33,11 +34,7 @@ def _read_image(path: Path, unchanged: bool = False) -> Optional[np.ndarray]:
     path = Path(path)
     if path.suffix == ".npy":
         return np.load(path, allow_pickle=False) if path.exists() else None
-    try:
-        import cv2 as cv
-    except ImportError as e:          # pragma: no cover - cv2 is absent in the build container
-        raise ImportError("reading TIFF images needs OpenCV (cv2); pass arrays in memory or use .npy files") from e
-    return cv.imread(str(path), cv.IMREAD_UNCHANGED) if unchanged else cv.imread(str(path))
+    return tiff_io.imread(path, tiff_io.IMREAD_UNCHANGED if unchanged else tiff_io.IMREAD_COLOR)     # cv.imread's contract
 
 
 def _std_path(path: Path) -> Path:
@@ -177,10 +174,7 @@ class ImageSet(object):
         """image_set.py:228-243: '<name> STD.tif' as float64, else the per-DN table fallback."""
         std_array = None
         if self.path is not None:
-            try:
-                std_array = _read_image(_std_path(self.path), unchanged=True)
-            except ImportError:
-                std_array = None
+            std_array = _read_image(_std_path(self.path), unchanged=True)
         if std_array is None:
             std_array = self.calculate_numerical_STD(STD_data)
         if std_array is None:
@@ -216,6 +210,46 @@ class ImageSet(object):
             flatSet.load_std_image()
         new_measurand = self.measurand.normalize_by_map(flatSet.measurand)
         return ImageSet(file_path=self.path, features=self.features, measurand=new_measurand)
+
+    def save_64bit(self, save_path: Optional[Path] = None, is_HDR: Optional[bool] = False,
+                   separate_channels: Optional[bool] = False):
+        """image_set.py:264-318: float64 TIFFs '<name>[ HDR].tif' and '<name>[ HDR] STD.tif' (or one file per channel,
+        '<name>[ HDR] <channel name>.tif')."""
+        file_path = self.path.parent.joinpath("64bit", self.path.name) if save_path is None else Path(save_path)
+        file_path.parent.mkdir(parents=True, exist_ok=True)
+        base = str(file_path).removesuffix(".tif")
+        acq_suffix, std_suffix = (" HDR.tif", " HDR STD.tif") if is_HDR else (".tif", " STD.tif")
+        val, std = self.to_numpy()
+        if not separate_channels:
+            tiff_io.imwrite(base + acq_suffix, val.astype(np.float64))
+            if std is not None:
+                tiff_io.imwrite(base + std_suffix, std.astype(np.float64))
+        else:
+            for c in range(val.shape[-1]):
+                name = gs.CH_STR.get(c, str(c))
+                tiff_io.imwrite(base + acq_suffix.replace(".tif", f" {name}.tif"), val[:, :, c])
+                if std is not None:
+                    tiff_io.imwrite(base + std_suffix.replace(".tif", f" {name}.tif"), std[:, :, c])
+
+    def save_8bit(self, save_path: Optional[Path] = None, force_8_bit: Optional[bool] = False):
+        """image_set.py:320-363: value image scaled to its maximum if that exceeds 1, rounded to uint8; the std image is
+        written as float64 unless force_8_bit."""
+        file_path = self.path.parent.joinpath("8bit", self.path.name) if save_path is None else Path(save_path)
+        file_path.parent.mkdir(parents=True, exist_ok=True)
+        val, std = self.to_numpy()
+        val = val.astype(np.float64, copy=True)
+        max_float = np.amax(val)
+        if max_float > 1:
+            val /= max_float
+        tiff_io.imwrite(file_path, np.around(val * gs.MAX_DN).astype(np.uint8))
+        if std is not None:
+            std = std.astype(np.float64, copy=True)
+            if force_8_bit:
+                max_float = np.amax(std)
+                if max_float > 1:
+                    std /= max_float
+                std = np.around(std * gs.MAX_DN).astype(np.uint8)
+            tiff_io.imwrite(str(file_path).removesuffix(".tif") + " STD.tif", std)
 
     def save_npy(self, save_path: Path, is_HDR: bool = False):
         """Host-side dump of val (and std) as .npy next to each other ('<name> HDR.npy', '<name> HDR STD.npy' -

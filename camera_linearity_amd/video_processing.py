@@ -108,3 +108,22 @@ def welford_algorithm(frame_sources: Union[Iterable, Sequence[Iterable]], ICRF: 
 
 def _looks_like_frame(x) -> bool:
     return x is None or (isinstance(x, (np.ndarray, torch.Tensor)) and x.ndim in (2, 3))
+
+
+def save_result(ret: dict, video_path) -> None:
+    """The file naming of process_video (video_processing.py:222-236): '<video>.mean.tif' / '<video>.std.tif'
+    next to the video, written with cv.imwrite's conventions."""
+    from pathlib import Path
+    from . import tiff_io
+    video_path = Path(video_path)
+    for key in ret:
+        if ret[key] is not None:
+            img = ret[key].cpu().numpy() if isinstance(ret[key], torch.Tensor) else ret[key]
+            tiff_io.imwrite(video_path.parent.joinpath(video_path.name.replace(".avi", f".{key}.tif")), img)
+
+
+def process_video(frame_source, video_path, ICRF: Optional[np.ndarray] = None, use_std: Optional[bool] = True):
+    """video_processing.py:222-236 for an already opened frame source."""
+    ret = welford_algorithm(frame_source, ICRF, use_std)
+    save_result(ret, video_path)
+    return ret

@@ -278,6 +278,16 @@ int hm_linearity_energy(const uint8_t* dn, const double* std /*nullable*/, const
                         int lower, int upper, int use_relative, int64_t n_pixels, int n_frames,
                         double* out_pairs /*nullable*/, double* out_energy, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * On-disk formats: host-side strip decoders for the TIFF files the reference exchanges with
+ * OpenCV (modules/image_set.py:214-243 cv.imread, :264-363 cv.imwrite). HOST pointers, no device work, re-entrant.
+ * Return the number of bytes written to dst, HM_EINVAL for a corrupt stream, HM_ESHAPE if dst_cap is too small.
+ *   hm_tiff_lzw_decode       TIFF 6.0 LZW (Compression 5), MSB-first 9..12-bit codes, libtiff's early change
+ *   hm_tiff_packbits_decode  PackBits (Compression 32773)
+ * ------------------------------------------------------------------------------------------ */
+int64_t hm_tiff_lzw_decode(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+int64_t hm_tiff_packbits_decode(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap);
+
 #ifdef __cplusplus
 }
 #endif

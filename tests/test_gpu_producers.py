@@ -216,3 +216,44 @@ def test_calibration_recovers_response(eng):
                                           vectorized=vectorized)
         assert icrf.shape == (256,) and n_it <= iters
         assert e < e0 / (10 if vectorized else 2), (vectorized, e, e0, e_true)
+
+
+# ------------------------------------------------------------------------------------------------ on-disk workflow (8f-4)
+def test_from_dir_path_tiff_workflow(eng, tmp_path):
+    """The reference's file workflow without cv2: an exposure series of 8-bit BGR TIFFs with float64 ' STD.tif' companions
+    (file-name grammar of modules/image_set.py:542-568) -> ExposureSeries.from_dir_path -> process_HDR_image ->
+    save_64bit(is_HDR=True) -> files that read back to the merged arrays; the merge equals the oracle on the same arrays."""
+    from camera_linearity_amd import tiff_io
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    frames, stds, t = orc.synthetic_stack(9, 4, 40, 56, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    for f, s, ti in zip(frames, stds, t):
+        name = f"{ti * 1000:g}ms bf 5x sample.tif"
+        tiff_io.imwrite(tmp_path / name, f)
+        tiff_io.imwrite(tmp_path / name.replace(".tif", " STD.tif"), s)
+    sets = ImageSet.multiple_from_path(tmp_path)
+    assert len(sets) == 4 and sorted(s.features["exposure"] for s in sets) == sorted(t.tolist())
+    assert all(s.features["illumination"] == "bf" and s.features["magnification"] == "5x" for s in sets)
+    series_list = ExposureSeries.from_dir_path(tmp_path)
+    series = series_list[0] if isinstance(series_list, list) else series_list
+    assert len(series.input_image_sets) == 4
+    series.process_HDR_image(icrf, diff)
+    val, std = series.merged_image_set.to_numpy()
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    np.testing.assert_allclose(val, ref["val"], rtol=1e-12)
+    np.testing.assert_allclose(std, ref["std"], rtol=1e-9)
+    out = tmp_path / "out" / "bf 5x sample.tif"
+    series.merged_image_set.save_64bit(out, is_HDR=True)
+    back = tiff_io.imread(tmp_path / "out" / "bf 5x sample HDR.tif", tiff_io.IMREAD_UNCHANGED)
+    back_std = tiff_io.imread(tmp_path / "out" / "bf 5x sample HDR STD.tif", tiff_io.IMREAD_UNCHANGED)
+    assert back.dtype == np.float64 and np.array_equal(back, val) and np.array_equal(back_std, std)
+    series.merged_image_set.save_8bit(tmp_path / "out8" / "bf 5x sample.tif")
+    v8 = tiff_io.imread(tmp_path / "out8" / "bf 5x sample.tif")
+    assert v8.dtype == np.uint8 and np.array_equal(v8, np.around(val / max(val.max(), 1.0) * 255).astype(np.uint8))
+    # the Welford producer's output files (video_processing.py:222-236)
+    from camera_linearity_amd.video_processing import process_video
+    clip = np.random.default_rng(1).integers(0, 256, (6, 10, 12, 3), dtype=np.uint8)
+    ret = process_video(clip, tmp_path / "clip 10ms.avi", None, True)
+    assert np.array_equal(tiff_io.imread(tmp_path / "clip 10ms.mean.tif"), ret["mean"])
+    assert np.array_equal(tiff_io.imread(tmp_path / "clip 10ms.std.tif"), ret["std"])
