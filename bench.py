@@ -36,6 +36,7 @@ WORKLOADS = {
     "cfg3flat": (7, 4096, 4096, True, "flat"),  # std + flat field
     "cfg3hot": (7, 4096, 4096, True, "hot"),    # std + dark hot-pixel maps
     "cfg4tile": (15, 1024, 8192, False, False),  # configs[3]: one of 8 row tiles of 15 x 8192 x 8192 x 3
+    "cfg4tilestd": (15, 1024, 8192, True, False),  # configs[3] "+std" variant of the same tile
 }
 
 

@@ -473,6 +473,9 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #ifndef HM_FB
 #define HM_FB 4
 #endif
+#ifndef HM_PIN_NF
+#define HM_PIN_NF 8      // std kernel: above this N, pass 2 re-derives its per-frame addresses (registers)
+#endif
 
 template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
@@ -625,10 +628,13 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
                 for (int i = 0; i < NF; ++i) {
                     const double it = a.inv_t[i];
                     const double* sp = a.sd[i] + a.in_off + sbase;                               // scalar base
+                    if (NF > HM_PIN_NF || !FLAT) asm volatile("" : "+s"(sp));     // keep base + 32-bit lane offset addressing (no per-frame VGPR address pairs)
                     const f64x2 sdv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(sp) + lane16));
+                    uint32_t packed = cur[i][s];
+                    if (NF > HM_PIN_NF || !FLAT) HM_PIN(packed);                  // re-extract the DNs here instead of keeping pass 1's indices alive
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const uint32_t dn = j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8);
+                        const uint32_t dn = j == 0 ? (packed & 255u) : (packed >> 8);
                         const double2 wdw = t_wdw[dn];
                         const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
                         const double w = wdw.x, dw = wdw.y, gg = gd.x;
