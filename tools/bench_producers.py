@@ -42,7 +42,12 @@ def prewarm():
     torch.cuda.synchronize()
 
 
+QUICK = "--quick" in sys.argv          # profiling runs: fewer repetitions
+
+
 def median_us(fn, iters=20, rounds=5):
+    if QUICK:
+        iters, rounds = 5, 1
     prewarm()
     return statistics.median(span(fn, iters) for _ in range(rounds))
 
