@@ -284,8 +284,9 @@ class ImageSet(object):
     def multiple_from_path(cls, path: Path):
         """image_set.py:482-501 (also picks up .npy files)."""
         out = []
+        root = path if hasattr(path, "glob") else Path(path)
         for pattern in ("*.tif", "*.npy"):
-            for file in sorted(Path(path).glob(pattern)):
+            for file in sorted(root.glob(pattern)):
                 if "STD" not in file.name:
                     out.append(cls(file_path=file))
         return out
