@@ -37,6 +37,8 @@ WORKLOADS = {
     "cfg3hot": (7, 4096, 4096, True, "hot"),    # std + dark hot-pixel maps
     "cfg4tile": (15, 1024, 8192, False, False),  # configs[3]: one of 8 row tiles of 15 x 8192 x 8192 x 3
     "cfg4tilestd": (15, 1024, 8192, True, False),  # configs[3] "+std" variant of the same tile
+    "cfg2f64": (7, 4096, 4096, False, False),   # 64-bit mode (image_set.py:225): float64 frames, analytic weights, computed index
+    "cfg3f64std": (7, 4096, 4096, True, False),  # 64-bit mode with std
 }
 
 
@@ -91,6 +93,8 @@ def main():
 
     n, H, W, with_std, corr = WORKLOADS[a.workload]
     frames, stds, t = synthetic_stack_device(7 + rank, n, H, W, device=dev, with_std=with_std)
+    if "f64" in a.workload:
+        frames = [engine.u8_to_unit(f) for f in frames]
     icrf, diff = synthetic_icrf()
     kw = {}
     if corr:

@@ -375,3 +375,45 @@ def test_sum_of_weights(eng, golden):
     S, S2 = eng.sum_of_weights([dev(f) for f in g["frames"]])
     close(host(S), g["S"], 1e-15 * 8)
     close(host(S2), g["S"] ** 2, 1e-14)
+
+
+def test_merge_captured_in_hip_graph(eng):
+    """hm_merge allocates nothing and does not synchronise (include/hdrmerge.h conventions), so a batch of small merges -
+    the launch-bound regime of config 1 - can be captured once into a hipGraph and replayed: same bits as eager launches,
+    also after the inputs change in place (the graph holds pointers, not data)."""
+    icrf, diff = orc.synthetic_icrf()
+    stacks = [orc.synthetic_stack(20 + k, 3, 64, 64, with_std=True) for k in range(8)]
+    flat = np.clip(np.around(255 * (0.8 + 0.05 * np.random.default_rng(0).random((64, 64, 3)))), 1, 255).astype(np.uint8)
+    dark = (np.random.default_rng(1).random((64, 64, 3)) < 0.01).astype(np.uint8) * 200
+    plans, inputs = [], []
+    for frames, stds, t in stacks:
+        fr = [torch.as_tensor(f, device="cuda") for f in frames]
+        inputs.append(fr)
+        sd = [torch.as_tensor(s, device="cuda") for s in stds]
+        plans.append(eng.plan_merge(fr, t, icrf, diff, sd, darks=[torch.as_tensor(dark, device="cuda")] * 3, dark_min=[13] * 3,
+                                    median_k=3))
+    for p in plans:                                   # eager reference (also warms the library's cached device queries)
+        p.launch()
+    torch.cuda.synchronize()
+    eager = [(p.outputs["val"].clone(), p.outputs["std"].clone()) for p in plans]
+    for p in plans:
+        p.outputs["val"].zero_(); p.outputs["std"].zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for p in plans:
+            p.launch()
+    g.replay()
+    torch.cuda.synchronize()
+    for p, (v, s) in zip(plans, eager):
+        assert torch.equal(p.outputs["val"], v) and torch.equal(p.outputs["std"], s)
+    # change one stack's frames in place and replay: the graph recomputes from the new bytes
+    for dst, src in zip(inputs[0], orc.synthetic_stack(99, 3, 64, 64)[0]):
+        dst.copy_(torch.as_tensor(src, device="cuda"))
+    plans[0].launch()
+    torch.cuda.synchronize()
+    want = plans[0].outputs["val"].clone()
+    assert not torch.equal(want, eager[0][0])
+    plans[0].outputs["val"].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plans[0].outputs["val"], want) and torch.equal(plans[1].outputs["val"], eager[1][0])
