@@ -673,6 +673,180 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// merge_u8_loop: the same work decomposition and arithmetic as merge_u8_fast with the frame count as a run-time
+// value, for 16 < N <= HM_MAX_FRAMES (the templated kernel is instantiated for N <= 16; before this kernel larger
+// stacks fell to merge_generic at 0.19-0.33 of the HBM roofline, tools/bench_n.py). Frames are consumed in chunks
+// of kLoopChunk: the chunk's ushort loads are issued together (frame pointers and 1/t come from the kernarg segment
+// through scalar loads with a uniform index), then its LDS gathers, then the accumulation in frame order. The std
+// variant re-reads the frame bytes in its second pass (L2 hits, 1 byte per element-frame) instead of keeping N
+// packed words in registers. No cross-group prefetch: the kernel stays under 64 VGPRs and relies on 8 waves/SIMD.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLoopChunk = 8;
+
+template <bool STD, bool FLAT, bool SUMW>
+__global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int C = 3;
+    constexpr int TAB = TAB_FUSED;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr uint32_t WPB = 4;
+    const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / kSub);
+    const uint32_t gstride = gridDim.x * WPB;
+    const int N = a.n_frames;
+
+    if constexpr (!STD) {
+        fill_val_tables<TAB>(lds, a);
+    } else {
+        double2* t_wdw = reinterpret_cast<double2*>(lds);
+        double2* t_gd = reinterpret_cast<double2*>(lds + 16 * 256);
+        for (int i = threadIdx.x; i < 256; i += 256) t_wdw[i] = double2{a.w_lut[i], a.dw_lut[i]};
+        for (int i = threadIdx.x; i < 256 * C; i += 256) t_gd[i] = double2{a.icrf[i], a.icrf_diff[i]};
+    }
+    double2* t_flat = reinterpret_cast<double2*>(lds + (STD ? kStdTabBytes : TabInfo<TAB>::bytes));
+    if constexpr (FLAT) {
+        for (int i = threadIdx.x; i < 256; i += 256) {
+            const double F = static_cast<double>(i) / 255.0;
+            t_flat[i] = double2{F, 1.0 / (F * F)};
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t g = blockIdx.x * WPB + wave; g < n_groups; g += gstride) {
+        const int64_t sbase = static_cast<int64_t>(g) * kSub;                 // relative to row0, scalar
+        const int64_t ibase = a.in_off + sbase;
+        const uint32_t c0 = (2u * (g + lane)) % 3u;
+        const uint32_t c1 = (c0 + 1u) % 3u;
+        const uint32_t coffs[2] = {STD ? c0 * 16u : chan_off<TAB>(c0), STD ? c1 * 16u : chan_off<TAB>(c1)};
+
+        double F[2] = {1.0, 1.0}, sF[2] = {0.0, 0.0}, iF2[2] = {1.0, 1.0};
+        if constexpr (FLAT) {
+            if (a.flat_u8) {
+                const uint32_t f = ld_u16(a.flat_u8 + sbase + lane2);
+                const double2 f0 = t_flat[f & 255u], f1 = t_flat[f >> 8];
+                F[0] = f0.x; iF2[0] = f0.y; F[1] = f1.x; iF2[1] = f1.y;
+            } else {
+                const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_f64 + sbase) + lane16));
+                F[0] = f.x; F[1] = f.y;
+                if (STD) { iF2[0] = 1.0 / (F[0] * F[0]); iF2[1] = 1.0 / (F[1] * F[1]); }
+            }
+            if (STD) {
+                const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_std + sbase) + lane16));
+                sF[0] = f.x; sF[1] = f.y;
+            }
+        }
+
+        double S[2] = {0.0, 0.0}, acc[2] = {0.0, 0.0}, var[2] = {0.0, 0.0};
+        if constexpr (!STD) {
+            for (int i0 = 0; i0 < N; i0 += kLoopChunk) {
+                uint32_t r[kLoopChunk];
+#pragma unroll
+                for (int k = 0; k < kLoopChunk; ++k)
+                    if (i0 + k < N) r[k] = ld_u16(static_cast<const uint8_t*>(a.frame[i0 + k]) + ibase + lane2);
+#pragma unroll
+                for (int k = 0; k < kLoopChunk; ++k) {
+                    if (i0 + k < N) {
+                        const double it = a.inv_t[i0 + k];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint32_t dn = j == 0 ? (r[k] & 255u) : (r[k] >> 8);
+                            double w, wg;
+                            gather_val<TAB>(lds, dn, coffs[j], w, wg);
+                            if (i0 + k == 0) { S[j] = w; acc[j] = wg * it; }
+                            else { S[j] += w; acc[j] = fma(wg, it, acc[j]); }            // exposure_series.py:340, :388
+                        }
+                    }
+                }
+            }
+            double val[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) val[j] = acc[j] / S[j];
+            if constexpr (FLAT) {
+                double dummy = 0.0;
+                flat_field_math(F[0], iF2[0], 0.0, a.ff_mean[c0], 0.0, false, val[0], dummy);
+                flat_field_math(F[1], iF2[1], 0.0, a.ff_mean[c1], 0.0, false, val[1], dummy);
+            }
+            if constexpr (SUMW) store2(a.out_sum_w + sbase, lane16, S[0], S[1]);
+            store2(a.out_val + sbase, lane16, val[0], val[1]);
+        } else {
+            const double2* t_wdw = reinterpret_cast<const double2*>(lds);
+            const char* t_gd = lds + 16 * 256;
+            // pass 1: S = sum_i w_i
+            for (int i0 = 0; i0 < N; i0 += kLoopChunk) {
+                uint32_t r[kLoopChunk];
+#pragma unroll
+                for (int k = 0; k < kLoopChunk; ++k)
+                    if (i0 + k < N) r[k] = ld_u16(static_cast<const uint8_t*>(a.frame[i0 + k]) + ibase + lane2);
+#pragma unroll
+                for (int k = 0; k < kLoopChunk; ++k) {
+                    if (i0 + k < N) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const double w = t_wdw[j == 0 ? (r[k] & 255u) : (r[k] >> 8)].x;
+                            if (i0 + k == 0) S[j] = w; else S[j] += w;
+                        }
+                    }
+                }
+            }
+            double invS[2], invS2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                invS[j] = 1.0 / S[j];
+                invS2[j] = 1.0 / (S[j] * S[j]);                          // 1 / S**2, exposure_series.py:343
+            }
+            // pass 2: the frame bytes again (cache hits) + the float64 std streams, two frames per step
+            for (int i0 = 0; i0 < N; i0 += 2) {
+                uint32_t r[2];
+                f64x2 sdv[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (i0 + k < N) {
+                        r[k] = ld_u16(static_cast<const uint8_t*>(a.frame[i0 + k]) + ibase + lane2);
+                        const double* sp = a.sd[i0 + k] + ibase;
+                        sdv[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(sp) + lane16));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (i0 + k < N) {
+                        const double it = a.inv_t[i0 + k];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint32_t dn = j == 0 ? (r[k] & 255u) : (r[k] >> 8);
+                            const double2 wdw = t_wdw[dn];
+                            const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
+                            const double w = wdw.x, dw = wdw.y, gg = gd.x;
+                            const double dg = gd.y * (j == 0 ? sdv[k].x : sdv[k].y);                       // measurand.py:512
+                            const double A = (dw * gg + w * dg) * invS[j] - ((dw * w) * gg) * invS2[j];   // :389
+                            const double term = (A * dg) * it;
+                            if (i0 + k == 0) { acc[j] = (w * gg) * it; var[j] = term * term; }
+                            else {
+                                acc[j] = fma(w * gg, it, acc[j]);                                          // :388
+                                var[j] = fma(term, term, var[j]);
+                            }
+                        }
+                    }
+                }
+            }
+            double val[2], so[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                val[j] = acc[j] / S[j];
+                so[j] = sqrt(var[j]);                                                                      // :394
+            }
+            if constexpr (FLAT) {
+                flat_field_math(F[0], iF2[0], sF[0], a.ff_mean[c0], a.ff_std_mean[c0], true, val[0], so[0]);
+                flat_field_math(F[1], iF2[1], sF[1], a.ff_mean[c1], a.ff_std_mean[c1], true, val[1], so[1]);
+            }
+            if constexpr (SUMW) store2(a.out_sum_w + sbase, lane16, S[0], S[1]);
+            store2(a.out_val + sbase, lane16, val[0], val[1]);
+            store2(a.out_std + sbase, lane16, so[0], so[1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int g_cu_count = 0;
@@ -794,6 +968,22 @@ static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool 
     return c.u * static_cast<int>(kSub);
 }
 
+static int launch_loop(const MergeK& k, bool with_std, hipStream_t st) {
+    const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
+    const int lds = (with_std ? kStdTabBytes : TabInfo<TAB_FUSED>::bytes) + (flat ? 16 * 256 : 0);
+    const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
+#define HM_LOOP(S, F, W) hipLaunchKernelGGL((merge_u8_loop<S, F, W>), dim3(grid), dim3(256), lds, st, k)
+    if (with_std) {
+        if (flat && sumw) HM_LOOP(true, true, true); else if (flat) HM_LOOP(true, true, false);
+        else if (sumw) HM_LOOP(true, false, true); else HM_LOOP(true, false, false);
+    } else {
+        if (flat && sumw) HM_LOOP(false, true, true); else if (flat) HM_LOOP(false, true, false);
+        else if (sumw) HM_LOOP(false, false, true); else HM_LOOP(false, false, false);
+    }
+#undef HM_LOOP
+    return launch_status();
+}
+
 static int launch_generic(const MergeK& k, bool f64in, bool with_std, hipStream_t st) {
     const unsigned grid = stream_grid(k.n_elems, 256, 8);
 #define HM_GEN(F, S) hipLaunchKernelGGL((merge_generic<F, S>), dim3(grid), dim3(256), 0, st, k)
@@ -899,7 +1089,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
     if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
-    bool fast = !f64in && C == 3 && N <= 16 && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
+    bool fast = !f64in && C == 3 && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
             fast = aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 2);
@@ -914,7 +1104,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (!fast) {
         rc = launch_generic(k, f64in, with_std, st);
     } else {
-        const int64_t grp = fast_group_elems(N, cfg, with_std, flat || g->out_sum_w);
+        const int64_t grp = N > 16 ? static_cast<int64_t>(kSub) : fast_group_elems(N, cfg, with_std, flat || g->out_sum_w);
         const int64_t body = (E / grp) * grp;
         if (body > 0) {
             MergeK kb = k;
@@ -924,7 +1114,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
                 HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
                 HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
 #undef HM_CASE
-                default: return HM_EUNSUPPORTED;
+                default: rc = launch_loop(kb, with_std, st); break;        // 16 < N <= HM_MAX_FRAMES: run-time frame count
             }
             if (rc != HM_OK) return rc;
         }

@@ -174,11 +174,11 @@ def test_hot_pixel_filter_standalone(eng):
 
 # ------------------------------------------------------------------ seeded stacks vs the oracle
 @pytest.mark.parametrize("n,h,w", [(1, 5, 7), (2, 16, 16), (7, 33, 29), (7, 64, 128), (15, 24, 40), (16, 9, 11),
-                                   (17, 8, 8), (32, 4, 6)])
+                                   (17, 8, 8), (32, 4, 6), (24, 40, 33), (32, 31, 50)])
 @pytest.mark.parametrize("with_std", [False, True])
 def test_merge_vs_oracle_sizes(eng, n, h, w, with_std):
-    """Covers the fast kernel (N <= 16, whole 256/512-element groups), its tail, and the generic kernel
-    (N > 16, tiny images)."""
+    """Covers the fast kernel (N <= 16, whole 256/512-element groups), its tail, the run-time-N kernel (N > 16) and
+    the generic kernel (tiny images, tails)."""
     frames, stds, t = orc.synthetic_stack(100 + n, n, h, w, with_std=with_std)
     icrf, diff = orc.synthetic_icrf()
     ref = orc.merge(frames, t, icrf, diff, stds=stds)
@@ -262,11 +262,12 @@ def test_hot_pixel_fixup_batches(eng, n, k, f64):
     close(host(out["sum_w"]), ref["S"], 1e-13)
 
 
+@pytest.mark.parametrize("n", [7, 17, 20, 32])
 @pytest.mark.parametrize("with_std", [False, True])
-def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std):
-    """variant < 0 forces merge_generic; it must reproduce merge_u8_fast bit for bit (shared operation sequence),
-    including flat field and sum-of-weights output."""
-    n, h, w = 7, 96, 130
+def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std, n):
+    """variant < 0 forces merge_generic; it must reproduce merge_u8_fast (N <= 16) and merge_u8_loop (run-time frame
+    count, 16 < N <= 32) bit for bit (shared operation sequence), including flat field and sum-of-weights output."""
+    h, w = 96, 130
     frames, stds, t = orc.synthetic_stack(77, n, h, w, with_std=with_std)
     icrf, diff = orc.synthetic_icrf()
     rng = np.random.default_rng(3)
@@ -281,6 +282,13 @@ def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std):
     b = eng.merge(fr, t, icrf, diff, sd, variant=-1, **kw)
     for key in a:
         assert torch.equal(a[key], b[key]), key
+    # and without the extras (the plain instantiations)
+    a = eng.merge(fr, t, icrf, diff, sd, variant=0)
+    b = eng.merge(fr, t, icrf, diff, sd, variant=-1)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    close(host(a["val"]), ref["val"], VAL_RTOL)
 
 
 @pytest.mark.parametrize("C", [1, 2, 4])
