@@ -683,11 +683,9 @@ __global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kLoopChunk = 8;
 
-template <bool STD, bool FLAT, bool SUMW>
+template <int C, bool STD, bool FLAT, bool SUMW>
 __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int C = 3;
-    constexpr int TAB = TAB_FUSED;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -697,14 +695,17 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
     const int N = a.n_frames;
 
     if constexpr (!STD) {
-        fill_val_tables<TAB>(lds, a);
+        for (int q = threadIdx.x; q < 256 * C; q += 256) {
+            const double w = a.w_lut[q / C];
+            reinterpret_cast<double2*>(lds)[q] = double2{w, w * a.icrf[q]};      // {w, w * g}, exposure_series.py:388
+        }
     } else {
         double2* t_wdw = reinterpret_cast<double2*>(lds);
         double2* t_gd = reinterpret_cast<double2*>(lds + 16 * 256);
         for (int i = threadIdx.x; i < 256; i += 256) t_wdw[i] = double2{a.w_lut[i], a.dw_lut[i]};
         for (int i = threadIdx.x; i < 256 * C; i += 256) t_gd[i] = double2{a.icrf[i], a.icrf_diff[i]};
     }
-    double2* t_flat = reinterpret_cast<double2*>(lds + (STD ? kStdTabBytes : TabInfo<TAB>::bytes));
+    double2* t_flat = reinterpret_cast<double2*>(lds + (STD ? 16 * 256 + 16 * 256 * C : 16 * 256 * C));
     if constexpr (FLAT) {
         for (int i = threadIdx.x; i < 256; i += 256) {
             const double F = static_cast<double>(i) / 255.0;
@@ -716,9 +717,9 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
     for (uint32_t g = blockIdx.x * WPB + wave; g < n_groups; g += gstride) {
         const int64_t sbase = static_cast<int64_t>(g) * kSub;                 // relative to row0, scalar
         const int64_t ibase = a.in_off + sbase;
-        const uint32_t c0 = (2u * (g + lane)) % 3u;
-        const uint32_t c1 = (c0 + 1u) % 3u;
-        const uint32_t coffs[2] = {STD ? c0 * 16u : chan_off<TAB>(c0), STD ? c1 * 16u : chan_off<TAB>(c1)};
+        const uint32_t c0 = C == 1 ? 0u : static_cast<uint32_t>((static_cast<uint64_t>(g) * (kSub % C) + lane2) % C);   // element % C
+        const uint32_t c1 = C == 1 ? 0u : (c0 + 1u) % C;
+        const uint32_t coffs[2] = {c0 * 16u, c1 * 16u};
 
         double F[2] = {1.0, 1.0}, sF[2] = {0.0, 0.0}, iF2[2] = {1.0, 1.0};
         if constexpr (FLAT) {
@@ -751,8 +752,8 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const uint32_t dn = j == 0 ? (r[k] & 255u) : (r[k] >> 8);
-                            double w, wg;
-                            gather_val<TAB>(lds, dn, coffs[j], w, wg);
+                            const double2 tw = *reinterpret_cast<const double2*>(lds + dn * (16u * C) + coffs[j]);
+                            const double w = tw.x, wg = tw.y;
                             if (i0 + k == 0) { S[j] = w; acc[j] = wg * it; }
                             else { S[j] += w; acc[j] = fma(wg, it, acc[j]); }            // exposure_series.py:340, :388
                         }
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
                         for (int j = 0; j < 2; ++j) {
                             const uint32_t dn = j == 0 ? (r[k] & 255u) : (r[k] >> 8);
                             const double2 wdw = t_wdw[dn];
-                            const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
+                            const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * (16u * C) + coffs[j]);
                             const double w = wdw.x, dw = wdw.y, gg = gd.x;
                             const double dg = gd.y * (j == 0 ? sdv[k].x : sdv[k].y);                       // measurand.py:512
                             const double A = (dw * gg + w * dg) * invS[j] - ((dw * w) * gg) * invS2[j];   // :389
@@ -968,11 +969,12 @@ static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool 
     return c.u * static_cast<int>(kSub);
 }
 
-static int launch_loop(const MergeK& k, bool with_std, hipStream_t st) {
+template <int C>
+static int launch_loop_c(const MergeK& k, bool with_std, hipStream_t st) {
     const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
-    const int lds = (with_std ? kStdTabBytes : TabInfo<TAB_FUSED>::bytes) + (flat ? 16 * 256 : 0);
+    const int lds = (with_std ? 16 * 256 + 16 * 256 * C : 16 * 256 * C) + (flat ? 16 * 256 : 0);
     const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
-#define HM_LOOP(S, F, W) hipLaunchKernelGGL((merge_u8_loop<S, F, W>), dim3(grid), dim3(256), lds, st, k)
+#define HM_LOOP(S, F, W) hipLaunchKernelGGL((merge_u8_loop<C, S, F, W>), dim3(grid), dim3(256), lds, st, k)
     if (with_std) {
         if (flat && sumw) HM_LOOP(true, true, true); else if (flat) HM_LOOP(true, true, false);
         else if (sumw) HM_LOOP(true, false, true); else HM_LOOP(true, false, false);
@@ -982,6 +984,15 @@ static int launch_loop(const MergeK& k, bool with_std, hipStream_t st) {
     }
 #undef HM_LOOP
     return launch_status();
+}
+
+static int launch_loop(const MergeK& k, bool with_std, hipStream_t st) {
+    switch (k.C) {
+        case 1: return launch_loop_c<1>(k, with_std, st);
+        case 2: return launch_loop_c<2>(k, with_std, st);
+        case 3: return launch_loop_c<3>(k, with_std, st);
+        default: return launch_loop_c<4>(k, with_std, st);
+    }
 }
 
 static int launch_generic(const MergeK& k, bool f64in, bool with_std, hipStream_t st) {
@@ -1089,7 +1100,8 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
     if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
-    bool fast = !f64in && C == 3 && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
+    bool fast = !f64in && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
+    const bool loop_kernel = N > 16 || C != 3;         // run-time-N / any-C streaming kernel instead of the N <= 16, C = 3 templates
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
             fast = aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 2);
@@ -1104,12 +1116,12 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (!fast) {
         rc = launch_generic(k, f64in, with_std, st);
     } else {
-        const int64_t grp = N > 16 ? static_cast<int64_t>(kSub) : fast_group_elems(N, cfg, with_std, flat || g->out_sum_w);
+        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : fast_group_elems(N, cfg, with_std, flat || g->out_sum_w);
         const int64_t body = (E / grp) * grp;
         if (body > 0) {
             MergeK kb = k;
             kb.n_elems = body;
-            switch (N) {
+            switch (loop_kernel ? 0 : N) {
 #define HM_CASE(n) case n: rc = launch_fast_nf<n>(kb, cfg, with_std, st); break;
                 HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
                 HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)

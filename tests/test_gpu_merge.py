@@ -289,21 +289,40 @@ def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std, n):
         assert torch.equal(a[key], b[key]), key
     ref = orc.merge(frames, t, icrf, diff, stds=stds)
     close(host(a["val"]), ref["val"], VAL_RTOL)
+    # and without the extras (the plain instantiations)
+    a = eng.merge(fr, t, icrf, diff, sd, variant=0)
+    b = eng.merge(fr, t, icrf, diff, sd, variant=-1)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    close(host(a["val"]), ref["val"], VAL_RTOL)
 
 
 @pytest.mark.parametrize("C", [1, 2, 4])
 @pytest.mark.parametrize("with_std", [False, True])
-def test_merge_other_channel_counts(eng, C, with_std):
-    """C != 3 takes the generic kernel (runtime channel count, HM_MAX_CHANNELS = 4)."""
-    n, h, w = 4, 9, 7
+@pytest.mark.parametrize("n,h,w", [(4, 9, 7), (5, 40, 52), (20, 33, 31)])
+def test_merge_other_channel_counts(eng, C, with_std, n, h, w):
+    """C != 3 (HM_MAX_CHANNELS = 4): whole 128-element groups stream through merge_u8_loop<C>, the rest through the
+    generic kernel; both against the oracle, and bit-identical to the all-generic result, with flat field and sum of
+    weights."""
     frames, stds, t = orc.synthetic_stack(300 + C, n, h, w, c=C, with_std=with_std)
     icrf = np.stack([np.linspace(0, 1, 256) ** (1.5 + 0.2 * k) for k in range(C)], axis=1)
     diff = orc.icrf_derivative(icrf)
     ref = orc.merge(frames, t, icrf, diff, stds=stds)
-    out = eng.merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds] if with_std else None)
+    fr = [dev(f) for f in frames]
+    sd = [dev(s) for s in stds] if with_std else None
+    out = eng.merge(fr, t, icrf, diff, sd)
     close(host(out["val"]), ref["val"], VAL_RTOL)
     if with_std:
         close(host(out["std"]), ref["std"], STD_RTOL)
+    rng = np.random.default_rng(C)
+    kw = dict(flat=dev(rng.integers(180, 230, size=(h, w, C)).astype(np.uint8)), ff_mean=[0.8, 0.81, 0.79, 0.82][:C], want_sum_w=True)
+    if with_std:
+        kw.update(flat_std=dev(np.full((h, w, C), 0.002)), ff_std_mean=[0.002] * C)
+    a_ = eng.merge(fr, t, icrf, diff, sd, variant=0, **kw)
+    b_ = eng.merge(fr, t, icrf, diff, sd, variant=-1, **kw)
+    for key in a_:
+        assert torch.equal(a_[key], b_[key]), key
 
 
 def test_merge_unaligned_tile_and_single_row(eng):
