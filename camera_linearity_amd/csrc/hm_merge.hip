@@ -848,6 +848,172 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// merge_f64_loop: float64 frames (the reference's 64-bit mode, image_set.py:225 / frames saved by save_64bit) with the
+// streaming decomposition of merge_u8_loop: lane l owns elements 2l, 2l+1 of a 128-element group, every frame / std /
+// output access is one 16-byte load or store per lane (1 KB contiguous per wave instruction). The weight is evaluated
+// analytically (measurand.py:615-616) and the LUT index is computed (round-half-even, wrap, :503), exactly as
+// merge_generic does; val-only needs one pass (S and the numerator accumulate together), std needs S first and
+// re-evaluates the weights in its second pass (frames re-read from cache; keeping the pass-1 weights of small
+// stacks in registers instead was measured slower: 139 VGPRs, 1 813 vs 1 704 us on 7 x 4096 x 4096 x 3). merge_generic evaluated exp() twice per
+// element-frame even for val-only and moved 8-byte pieces: 1 307 -> see DESIGN.md 8 for the numbers.
+// ------------------------------------------------------------------------------------------------
+constexpr int kF64Chunk = 4;
+
+__device__ __forceinline__ uint32_t lut_index_f64(double v) {
+    return static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;          // measurand.py:503
+}
+
+template <int C, bool STD, bool FLAT, bool SUMW>
+__global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr uint32_t WPB = 4;
+    const uint32_t n_groups = static_cast<uint32_t>(a.n_elems / kSub);
+    const uint32_t gstride = gridDim.x * WPB;
+    const int N = a.n_frames;
+    double2* t_gd = reinterpret_cast<double2*>(lds);                              // {g, d} per (dn, c)
+    for (int i = threadIdx.x; i < 256 * C; i += 256) t_gd[i] = double2{a.icrf[i], STD ? a.icrf_diff[i] : 0.0};
+    double2* t_flat = reinterpret_cast<double2*>(lds + 16 * 256 * C);
+    if constexpr (FLAT) {
+        for (int i = threadIdx.x; i < 256; i += 256) {
+            const double F = static_cast<double>(i) / 255.0;
+            t_flat[i] = double2{F, 1.0 / (F * F)};
+        }
+    }
+    __syncthreads();
+    auto ld2 = [&](const double* base) -> f64x2 {
+        return __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(base) + lane16));
+    };
+
+    for (uint32_t g = blockIdx.x * WPB + wave; g < n_groups; g += gstride) {
+        const int64_t sbase = static_cast<int64_t>(g) * kSub;
+        const int64_t ibase = a.in_off + sbase;
+        const uint32_t c0 = C == 1 ? 0u : static_cast<uint32_t>((static_cast<uint64_t>(g) * (kSub % C) + lane2) % C);
+        const uint32_t c1 = C == 1 ? 0u : (c0 + 1u) % C;
+        const uint32_t cs[2] = {c0, c1};
+
+        double F[2] = {1.0, 1.0}, sF[2] = {0.0, 0.0}, iF2[2] = {1.0, 1.0};
+        if constexpr (FLAT) {
+            if (a.flat_u8) {
+                const uint32_t f = ld_u16(a.flat_u8 + sbase + lane2);
+                const double2 f0 = t_flat[f & 255u], f1 = t_flat[f >> 8];
+                F[0] = f0.x; iF2[0] = f0.y; F[1] = f1.x; iF2[1] = f1.y;
+            } else {
+                const f64x2 f = ld2(a.flat_f64 + sbase);
+                F[0] = f.x; F[1] = f.y;
+                if (STD) { iF2[0] = 1.0 / (F[0] * F[0]); iF2[1] = 1.0 / (F[1] * F[1]); }
+            }
+            if (STD) { const f64x2 f = ld2(a.flat_std + sbase); sF[0] = f.x; sF[1] = f.y; }
+        }
+
+        double S[2] = {0.0, 0.0}, acc[2] = {0.0, 0.0}, var[2] = {0.0, 0.0};
+        if constexpr (!STD) {
+            for (int i0 = 0; i0 < N; i0 += kF64Chunk) {
+                f64x2 v[kF64Chunk];
+#pragma unroll
+                for (int k = 0; k < kF64Chunk; ++k)
+                    if (i0 + k < N) v[k] = ld2(static_cast<const double*>(a.frame[i0 + k]) + ibase);
+#pragma unroll
+                for (int k = 0; k < kF64Chunk; ++k) {
+                    if (i0 + k < N) {
+                        const double it = a.inv_t[i0 + k];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const double x = j == 0 ? v[k].x : v[k].y;
+                            const double dv = x - 0.5;
+                            const double w = exp(-30.0 * (dv * dv));                            // measurand.py:615
+                            const double gg = t_gd[lut_index_f64(x) * C + cs[j]].x;
+                            const double wg = w * gg;
+                            if (i0 + k == 0) { S[j] = w; acc[j] = wg * it; }
+                            else { S[j] += w; acc[j] = fma(wg, it, acc[j]); }                   // exposure_series.py:340, :388
+                        }
+                    }
+                }
+            }
+            double val[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) val[j] = acc[j] / S[j];
+            if constexpr (FLAT) {
+                double dummy = 0.0;
+                flat_field_math(F[0], iF2[0], 0.0, a.ff_mean[c0], 0.0, false, val[0], dummy);
+                flat_field_math(F[1], iF2[1], 0.0, a.ff_mean[c1], 0.0, false, val[1], dummy);
+            }
+            if constexpr (SUMW) store2(a.out_sum_w + sbase, lane16, S[0], S[1]);
+            store2(a.out_val + sbase, lane16, val[0], val[1]);
+        } else {
+            double invS[2], invS2[2];
+            // one frame of pass 2 (measurand.py:512,616; exposure_series.py:388-389) given its weight
+            auto pass2 = [&](int i, int j, double x, double w, double s, double it) {
+                const double dw = (-60.0 * (x - 0.5)) * w;                                      // measurand.py:616
+                const double2 gd = t_gd[lut_index_f64(x) * C + cs[j]];
+                const double gg = gd.x;
+                const double wg = w * gg;
+                const double dg = gd.y * s;                                                     // measurand.py:512
+                const double A = (dw * gg + w * dg) * invS[j] - ((dw * w) * gg) * invS2[j];     // :389
+                const double term = (A * dg) * it;
+                if (i == 0) { acc[j] = wg * it; var[j] = term * term; }
+                else { acc[j] = fma(wg, it, acc[j]); var[j] = fma(term, term, var[j]); }
+            };
+            {
+                for (int i0 = 0; i0 < N; i0 += kF64Chunk) {                                    // pass 1: S
+                    f64x2 v[kF64Chunk];
+#pragma unroll
+                    for (int k = 0; k < kF64Chunk; ++k)
+                        if (i0 + k < N) v[k] = ld2(static_cast<const double*>(a.frame[i0 + k]) + ibase);
+#pragma unroll
+                    for (int k = 0; k < kF64Chunk; ++k) {
+                        if (i0 + k < N) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const double dv = (j == 0 ? v[k].x : v[k].y) - 0.5;
+                                const double w = exp(-30.0 * (dv * dv));
+                                if (i0 + k == 0) S[j] = w; else S[j] += w;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { invS[j] = 1.0 / S[j]; invS2[j] = 1.0 / (S[j] * S[j]); }
+                for (int i0 = 0; i0 < N; i0 += 2) {                                            // pass 2: weights re-evaluated
+                    f64x2 v[2], sdv[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (i0 + k < N) {
+                            v[k] = ld2(static_cast<const double*>(a.frame[i0 + k]) + ibase);
+                            sdv[k] = ld2(a.sd[i0 + k] + ibase);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if (i0 + k < N) {
+                            const double it = a.inv_t[i0 + k];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const double x = j == 0 ? v[k].x : v[k].y;
+                                const double dv = x - 0.5;
+                                pass2(i0 + k, j, x, exp(-30.0 * (dv * dv)), j == 0 ? sdv[k].x : sdv[k].y, it);
+                            }
+                        }
+                    }
+                }
+            }
+            double val[2], so[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { val[j] = acc[j] / S[j]; so[j] = sqrt(var[j]); }
+            if constexpr (FLAT) {
+                flat_field_math(F[0], iF2[0], sF[0], a.ff_mean[c0], a.ff_std_mean[c0], true, val[0], so[0]);
+                flat_field_math(F[1], iF2[1], sF[1], a.ff_mean[c1], a.ff_std_mean[c1], true, val[1], so[1]);
+            }
+            if constexpr (SUMW) store2(a.out_sum_w + sbase, lane16, S[0], S[1]);
+            store2(a.out_val + sbase, lane16, val[0], val[1]);
+            store2(a.out_std + sbase, lane16, so[0], so[1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static int g_cu_count = 0;
@@ -986,6 +1152,32 @@ static int launch_loop_c(const MergeK& k, bool with_std, hipStream_t st) {
     return launch_status();
 }
 
+template <int C>
+static int launch_f64_c(const MergeK& k, bool with_std, hipStream_t st) {
+    const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
+    const int lds = 16 * 256 * C + (flat ? 16 * 256 : 0);
+    const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
+#define HM_F64(S, F, W) hipLaunchKernelGGL((merge_f64_loop<C, S, F, W>), dim3(grid), dim3(256), lds, st, k)
+    if (with_std) {
+        if (flat && sumw) HM_F64(true, true, true); else if (flat) HM_F64(true, true, false);
+        else if (sumw) HM_F64(true, false, true); else HM_F64(true, false, false);
+    } else {
+        if (flat && sumw) HM_F64(false, true, true); else if (flat) HM_F64(false, true, false);
+        else if (sumw) HM_F64(false, false, true); else HM_F64(false, false, false);
+    }
+#undef HM_F64
+    return launch_status();
+}
+
+static int launch_f64(const MergeK& k, bool with_std, hipStream_t st) {
+    switch (k.C) {
+        case 1: return launch_f64_c<1>(k, with_std, st);
+        case 2: return launch_f64_c<2>(k, with_std, st);
+        case 3: return launch_f64_c<3>(k, with_std, st);
+        default: return launch_f64_c<4>(k, with_std, st);
+    }
+}
+
 static int launch_loop(const MergeK& k, bool with_std, hipStream_t st) {
     switch (k.C) {
         case 1: return launch_loop_c<1>(k, with_std, st);
@@ -1100,11 +1292,12 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
     if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
-    bool fast = !f64in && g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
-    const bool loop_kernel = N > 16 || C != 3;         // run-time-N / any-C streaming kernel instead of the N <= 16, C = 3 templates
+    bool fast = g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
+    const bool loop_kernel = f64in || N > 16 || C != 3;         // run-time-N / any-C streaming kernel instead of the N <= 16, C = 3 templates
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
-            fast = aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 2);
+            fast = f64in ? aligned(static_cast<const double*>(k.frame[i]) + k.in_off, 16)
+                         : aligned(static_cast<const uint8_t*>(k.frame[i]) + k.in_off, 2);
             if (fast && with_std) fast = aligned(k.sd[i] + k.in_off, 16);
         }
         fast = fast && aligned(k.out_val, 16) && (!k.out_std || aligned(k.out_std, 16)) &&
@@ -1126,14 +1319,14 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
                 HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
                 HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
 #undef HM_CASE
-                default: rc = launch_loop(kb, with_std, st); break;        // 16 < N <= HM_MAX_FRAMES: run-time frame count
+                default: rc = f64in ? launch_f64(kb, with_std, st) : launch_loop(kb, with_std, st); break;   // run-time frame count
             }
             if (rc != HM_OK) return rc;
         }
         if (body < E) {                                    // tail: less than one group
             MergeK kt = k;
             kt.elem0 = body; kt.n_elems = E - body;
-            rc = launch_generic(kt, false, with_std, st);
+            rc = launch_generic(kt, f64in, with_std, st);
         }
     }
     if (rc != HM_OK) return rc;

@@ -444,3 +444,36 @@ def test_merge_captured_in_hip_graph(eng):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(plans[0].outputs["val"], want) and torch.equal(plans[1].outputs["val"], eager[1][0])
+
+
+@pytest.mark.parametrize("n,C", [(3, 3), (7, 3), (20, 3), (5, 1), (6, 4)])
+@pytest.mark.parametrize("with_std", [False, True])
+def test_f64_streaming_kernel(eng, with_std, n, C):
+    """float64 frames (64-bit mode): merge_f64_loop against the oracle (analytic weights, computed index incl. .5 ties and
+    values off the DN grid) and bit-identical to merge_generic (variant < 0), with and without flat field / sum of weights."""
+    h, w = 48, 70
+    rng = np.random.default_rng(n * 10 + C)
+    v = [rng.random((h, w, C)) for _ in range(n)]
+    v[0].reshape(-1)[:64] = (np.arange(64) + 0.5) / 255                  # exact .5 ties where representable
+    v[n - 1].reshape(-1)[:16] = 1.0 + rng.random(16) * 0.004             # rounds to 255 or wraps to 0
+    stds = [0.01 * (1 + rng.random((h, w, C))) for _ in range(n)] if with_std else None
+    t = 1e-3 * 1.6 ** np.arange(n)
+    icrf = np.stack([np.linspace(0, 1, 256) ** (1.6 + 0.2 * k) for k in range(C)], axis=1)
+    diff = orc.icrf_derivative(icrf)
+    ref = orc.merge(v, t, icrf, diff, stds=stds)
+    fr = [dev(x) for x in v]
+    sd = [dev(s) for s in stds] if with_std else None
+    a = eng.merge(fr, t, icrf, diff, sd, variant=0)
+    b = eng.merge(fr, t, icrf, diff, sd, variant=-1)
+    close(host(a["val"]), ref["val"], 1e-11)
+    if with_std:
+        close(host(a["std"]), ref["std"], STD_RTOL)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+    kw = dict(flat=dev(rng.integers(180, 230, size=(h, w, C)).astype(np.uint8)), ff_mean=[0.8, 0.81, 0.79, 0.82][:C], want_sum_w=True)
+    if with_std:
+        kw.update(flat_std=dev(np.full((h, w, C), 0.002)), ff_std_mean=[0.002] * C)
+    a = eng.merge(fr, t, icrf, diff, sd, variant=0, **kw)
+    b = eng.merge(fr, t, icrf, diff, sd, variant=-1, **kw)
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
