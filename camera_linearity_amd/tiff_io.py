@@ -67,6 +67,8 @@ def _read_ifd(buf: memoryview, bo: str, big: bool, off: int):
         size = _TYPE_SIZES.get(typ)
         if size is None:
             continue
+        if size * cnt > len(buf):
+            raise TiffError(f"TIFF tag {tag} claims {cnt} values, more than the file holds")
         if size * cnt > inline:
             (voff,) = struct.unpack_from(bo + ("Q" if big else "I"), buf, voff)
         if typ in (5, 10):
@@ -96,9 +98,17 @@ def _decode_strip(data: bytes, compression: int, expected: int) -> bytes:
 
 
 def read_tiff(path) -> np.ndarray:
-    """First image of a TIFF file as stored: (H, W) or (H, W, S) in FILE sample order (RGB), file dtype."""
+    """First image of a TIFF file as stored: (H, W) or (H, W, S) in FILE sample order (RGB), file dtype.
+    Malformed files raise TiffError (a ValueError)."""
     with open(path, "rb") as f:
         buf = memoryview(f.read())
+    try:
+        return _read_tiff(buf)
+    except (struct.error, IndexError, zlib.error, OverflowError, MemoryError) as e:
+        raise TiffError(f"malformed TIFF file {path}: {e}") from e
+
+
+def _read_tiff(buf: memoryview) -> np.ndarray:
     if len(buf) < 8:
         raise TiffError("not a TIFF file (too short)")
     bo = {b"II": "<", b"MM": ">"}.get(bytes(buf[:2]))

@@ -168,3 +168,26 @@ def test_lzw_decoder_direct():
     pb = bytes([2, 1, 2, 3, 0xFE, 9, 0x80, 0, 7])                         # literal 1 2 3, 9 x3, no-op, literal 7
     n = nat.lib.hm_tiff_packbits_decode(pb, len(pb), out, 16)
     assert bytes(out[:n]) == bytes([1, 2, 3, 9, 9, 9, 7])
+
+
+def test_truncated_and_garbage_directories(tmp_path):
+    """Truncated files and directory entries that point outside the file are reported as ValueError, not crashes."""
+    img = sample_image(60, 70)
+    p = tmp_path / "t.tif"
+    T.imwrite(p, img)
+    raw = p.read_bytes()
+    for cut in (6, 9, len(raw) // 2, len(raw) - 7):
+        p.write_bytes(raw[:cut])
+        with pytest.raises(ValueError):
+            T.read_tiff(p)
+    bad = bytearray(raw)
+    ifd = struct.unpack_from("<I", raw, 4)[0]
+    struct.pack_into("<I", bad, ifd + 2 + 4, 0x7FFFFFF0)            # first entry: absurd value count
+    p.write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        T.read_tiff(p)
+    bad = bytearray(raw)
+    struct.pack_into("<I", bad, 4, len(raw) + 1000)                   # IFD offset beyond the file
+    p.write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        T.read_tiff(p)
