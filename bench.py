@@ -54,6 +54,24 @@ def cpu_baseline(frames, t, icrf, diff, stds, band_rows):
     return out, dt
 
 
+def cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads):
+    """The same oracle, row-tiled over a thread pool (NumPy releases the GIL inside its element-wise loops): the all-core
+    number SURVEY.md 8(d) asks to show beside the single-thread one. Bands of 128 rows."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import hdr_oracle as orc
+    fh = [f[:rows].cpu().numpy() for f in frames]
+    sh = None if stds is None else [s[:rows].cpu().numpy() for s in stds]
+    bands = [(r, min(r + 128, rows)) for r in range(0, rows, 128)]
+
+    def one(b):
+        r0, r1 = b
+        orc.merge([f[r0:r1] for f in fh], t, icrf, diff, stds=None if sh is None else [s[r0:r1] for s in sh])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(one, bands))
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +181,11 @@ def main():
                "sample": f"rows 0..{rows - 1} of the bench stack ({n}x{rows}x{W}x3, {dt:.1f} s), NumPy oracle, 1 thread of "
                          f"{os.cpu_count()} host cores",
                "gpu_vs_oracle_max_rel_err": max_rel, "parity_ok": bool(max_rel <= 1e-12)}
+        threads = min(16, os.cpu_count() or 1)          # the one-GPU box's CPU share
+        if threads > 1:
+            dt_t = cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads)
+            cpu["threaded"] = {"value": round(rows * W / dt_t / 1e6, 4), "unit": "Mpix/s", "cores": threads,
+                               "sample": f"same rows, 128-row bands on a {threads}-thread pool ({dt_t:.1f} s)"}
 
     if rank == 0:
         achieved = alg_bytes / avg_us / 1e3          # GB/s
