@@ -477,8 +477,14 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #define HM_PIN_NF 8      // std kernel: above this N, pass 2 re-derives its per-frame addresses (registers)
 #endif
 
+#ifdef HM_WAVES          /* experiment knob (tools/build_alt.sh): ask the register allocator for this many waves per SIMD */
+#define HM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(HM_WAVES, HM_WAVES)))
+#else
+#define HM_WAVES_ATTR
+#endif
+
 template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void merge_u8_fast(const MergeK a) {
+__global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const MergeK a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int C = 3;
     constexpr uint32_t GROUP = U * kSub;
