@@ -477,3 +477,30 @@ def test_f64_streaming_kernel(eng, with_std, n, C):
     b = eng.merge(fr, t, icrf, diff, sd, variant=-1, **kw)
     for key in a:
         assert torch.equal(a[key], b[key]), key
+
+
+def test_merge_special_values(eng):
+    """NaN / inf in the std frames, an all-dark and an all-saturated pixel column, an ICRF with values above 1 and a
+    non-monotonic ICRF: the kernels propagate what NumPy propagates (same NaN positions, same finite values)."""
+    n, h, w = 5, 16, 40
+    frames, stds, t = orc.synthetic_stack(55, n, h, w, with_std=True)
+    for f in frames:
+        f[:, 0] = 0          # all-dark column: radiance exactly 0 with ICRF[0] = 0
+        f[:, 1] = 255        # all-saturated column
+    stds[1][2, 3, 1] = np.nan
+    stds[3][4, 5, 2] = np.inf
+    stds[0][6, 7, 0] = 0.0
+    icrf, _ = orc.synthetic_icrf()
+    icrf = icrf * 1.7
+    icrf[100:110, 1] = icrf[100:110, 1][::-1]           # locally decreasing
+    diff = orc.icrf_derivative(icrf)
+    with np.errstate(all="ignore"):
+        ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    out = eng.merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds])
+    val, std = host(out["val"]), host(out["std"])
+    assert np.array_equal(np.isnan(std), np.isnan(ref["std"])) and np.array_equal(np.isinf(std), np.isinf(ref["std"]))
+    assert np.isnan(std[2, 3, 1]) and not np.isfinite(std[4, 5, 2])
+    ok = np.isfinite(ref["std"])
+    close(std[ok], ref["std"][ok], STD_RTOL)
+    close(val, ref["val"], VAL_RTOL)
+    assert (val[:, 0] == 0).all()
