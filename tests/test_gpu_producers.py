@@ -257,3 +257,39 @@ def test_from_dir_path_tiff_workflow(eng, tmp_path):
     ret = process_video(clip, tmp_path / "clip 10ms.avi", None, True)
     assert np.array_equal(tiff_io.imread(tmp_path / "clip 10ms.mean.tif"), ret["mean"])
     assert np.array_equal(tiff_io.imread(tmp_path / "clip 10ms.std.tif"), ret["std"])
+
+
+# ------------------------------------------------------------------------------------------------ host-to-host pipeline
+@pytest.mark.parametrize("with_std,depth,count", [(False, 2, 5), (True, 3, 4), (False, 2, 1)])
+def test_merge_pipeline_matches_oracle(eng, with_std, depth, count):
+    """MergePipeline (H2D, merge and D2H of consecutive stacks overlapped on three streams): every stack's result equals the
+    oracle's, in order, for more stacks than slots (slot reuse) and for a single stack."""
+    from camera_linearity_amd.pipeline import MergePipeline
+    n, h, w = 4, 40, 64
+    icrf, diff = orc.synthetic_icrf()
+    stacks = [orc.synthetic_stack(40 + k, n, h, w, with_std=with_std) for k in range(count)]
+    t = stacks[0][2]
+    pipe = MergePipeline(n, h, w, t, icrf, diff, with_std=with_std, depth=depth)
+    res = pipe.merge_many([s[0] for s in stacks], [s[1] for s in stacks] if with_std else None)
+    assert len(res) == count
+    for (val, std), (frames, stds, _) in zip(res, stacks):
+        ref = orc.merge(frames, t, icrf, diff, stds=stds)
+        np.testing.assert_allclose(val, ref["val"], rtol=1e-12)
+        if with_std:
+            np.testing.assert_allclose(std, ref["std"], rtol=1e-9)
+        else:
+            assert std is None
+    # the generator interface: results arrive in order and the pipeline can be driven again
+    def fill(k, fv, sv):
+        if k >= 3:
+            return False
+        for d, src in zip(fv, stacks[0][0]):
+            np.copyto(d, src)
+        if sv is not None:
+            for d, src in zip(sv, stacks[0][1]):
+                np.copyto(d, src)
+        return True
+    seen = [k for k, _, _ in pipe.run(fill)]
+    assert seen == [0, 1, 2]
+    with pytest.raises(ValueError):
+        MergePipeline(n, h, w, t, icrf, diff, depth=1)
