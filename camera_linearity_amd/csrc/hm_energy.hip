@@ -35,6 +35,14 @@ struct EnergyK {
     double t[HM_MAX_FRAMES];
 };
 
+// pixel-major variant (N <= kEnergyRegFrames): per-pair ratio t_i / t_j and its reciprocal from the host
+constexpr int kEnergyRegFrames = 8;
+constexpr int kEnergyRegPairs = kEnergyRegFrames * (kEnergyRegFrames - 1) / 2;
+struct EnergyPairs {
+    double ratio[kEnergyRegPairs];
+    double inv_ratio[kEnergyRegPairs];
+};
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -105,6 +113,88 @@ __global__ __launch_bounds__(256) void k_energy_partial(const EnergyK a) {
     }
 }
 
+// Pixel-major evaluation for N <= 8 frames: a thread owns pixels, reads their N samples (and stds) once, maps them
+// through the candidate's ICRF and evaluates ALL N(N-1)/2 pairs from registers, with the per-pair sums in registers
+// too (2 x 28 float64 at most). Against the pair-major kernel above this removes the N-fold re-reads of the stack
+// (27 GB of HBM traffic per 75-candidate launch on a 1024 x 1024 x 7 stack, profiles/r01e_producers_pmc.json) and
+// the four IEEE divisions + square root per pair-pixel: 1 / v_j is formed once per (pixel, frame), 1 / (v_j ratio) is
+// a product, and the weight 1 / sigma is one reciprocal square root. Those products differ from the reference's
+// quotients by an ulp or two per term (tests: 1e-12 relative on the pair results).
+template <int N, bool STD>
+__global__ __launch_bounds__(256) void k_energy_pixel(const EnergyK a, const EnergyPairs pr) {
+    constexpr int P = N * (N - 1) / 2;
+    __shared__ double lut[256];
+    __shared__ double red[4][2 * P];
+    const int b = blockIdx.y;
+    const int pairs = P;
+    auto out_of = [&](int p) { return a.partial + ((static_cast<int64_t>(b) * pairs + p) * a.chunks + blockIdx.x) * 2; };
+    if (a.valid && !a.valid[b]) {
+        if (threadIdx.x < P) { double* o = out_of(threadIdx.x); o[0] = 0.0; o[1] = 0.0; }
+        return;
+    }
+    lut[threadIdx.x] = a.icrf[static_cast<int64_t>(b) * 256 + threadIdx.x];
+    __syncthreads();
+    const double lo = lut[a.lower], hi = lut[a.upper];
+    const bool rel = a.relative != 0;
+    double num[P], den[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { num[p] = 0.0; den[p] = 0.0; }
+
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t px = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; px < a.P; px += stride) {
+        const uint8_t* q = a.dn + px * N;
+        double v[N], rv[N], s[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double x = lut[q[i]];
+            if (x < lo || x > hi) x = __builtin_nan("");                       // :96-97
+            v[i] = x;
+            rv[i] = 1.0 / x;
+            s[i] = STD ? a.sd[px * N + i] : 0.0;
+        }
+        int p = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = i + 1; j < N; ++j, ++p) {
+                const double ratio = pr.ratio[p];
+                const double scaled = v[j] * ratio;                             // :111
+                double d = v[i] - scaled;                                        // :114
+                double inv_s = 0.0;
+                if (rel) { inv_s = rv[j] * pr.inv_ratio[p]; d = d * inv_s; }     // :117  d / scaled
+                const double ad = fabs(d);                                       // :120
+                if (STD) {
+                    double qq;
+                    if (rel) {
+                        const double u = s[i] * inv_s;                           // s_i / scaled
+                        const double w2 = ((v[i] * s[j]) * inv_s) * rv[j];       // (v_i s_j) / (ratio v_j^2)        :127
+                        qq = u * u + w2 * w2;
+                    } else {
+                        const double w2 = ratio * s[j];
+                        qq = s[i] * s[i] + w2 * w2;                              // :129
+                    }
+                    const double w = rsqrt(qq);                                  // 1 / sigma
+                    const bool ok = isfinite(ad) && qq != 0.0 && w == w;         // :133-134, general_functions.py:164
+                    if (ok) { num[p] += ad * w; den[p] += w; }
+                } else {
+                    if (ad == ad) { num[p] += ad; den[p] += 1.0; }               // :138
+                }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const double s0 = wave_sum(num[p]), s1 = wave_sum(den[p]);
+        if (lane == 0) { red[wave][2 * p] = s0; red[wave][2 * p + 1] = s1; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * P) {
+        const int p = threadIdx.x >> 1, k = threadIdx.x & 1;
+        out_of(p)[k] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
 // one wave per candidate: pair results (chunks summed in order) and the NaN-ignoring mean over pairs
 __global__ __launch_bounds__(64) void k_energy_final(const double* __restrict__ partial, const uint8_t* __restrict__ valid,
                                                      int pairs, int chunks, double* __restrict__ out_pairs,
@@ -159,9 +249,26 @@ extern "C" int hm_linearity_energy(const uint8_t* dn, const double* std, const d
     k.P = n_pixels; k.N = n_frames; k.lower = lower; k.upper = upper; k.relative = use_relative ? 1 : 0;
     k.chunks = energy_chunks(n_pixels);
     for (int i = 0; i < n_frames; ++i) k.t[i] = exposures[i];
-    const dim3 grid(k.chunks, pairs, n_candidates);
-    if (std) hipLaunchKernelGGL(k_energy_partial<true>, grid, dim3(256), 0, as_stream(stream), k);
-    else     hipLaunchKernelGGL(k_energy_partial<false>, grid, dim3(256), 0, as_stream(stream), k);
+    // pixel-major kernel when there are enough candidates (or few enough pixels) for chunks x candidates workgroups to
+    // fill the chip; a lone candidate on a large stack keeps the pair-major kernel's pairs x chunks workgroups
+    if (n_frames <= kEnergyRegFrames && (n_candidates >= 8 || n_pixels <= 16384)) {
+        EnergyPairs pr{};
+        int p = 0;
+        for (int i = 0; i < n_frames; ++i)
+            for (int j = i + 1; j < n_frames; ++j, ++p) {
+                pr.ratio[p] = exposures[i] / exposures[j];                       // :100
+                pr.inv_ratio[p] = 1.0 / pr.ratio[p];
+            }
+        const dim3 grid(k.chunks, n_candidates);
+#define HM_EPX(n) case n: if (std) hipLaunchKernelGGL((k_energy_pixel<n, true>), grid, dim3(256), 0, as_stream(stream), k, pr); \
+                          else hipLaunchKernelGGL((k_energy_pixel<n, false>), grid, dim3(256), 0, as_stream(stream), k, pr); break;
+        switch (n_frames) { HM_EPX(2) HM_EPX(3) HM_EPX(4) HM_EPX(5) HM_EPX(6) HM_EPX(7) HM_EPX(8) default: return HM_EUNSUPPORTED; }
+#undef HM_EPX
+    } else {
+        const dim3 grid(k.chunks, pairs, n_candidates);
+        if (std) hipLaunchKernelGGL(k_energy_partial<true>, grid, dim3(256), 0, as_stream(stream), k);
+        else     hipLaunchKernelGGL(k_energy_partial<false>, grid, dim3(256), 0, as_stream(stream), k);
+    }
     int rc = launch_status();
     if (rc != HM_OK) return rc;
     hipLaunchKernelGGL(k_energy_final, dim3(n_candidates), dim3(64), 0, as_stream(stream),
