@@ -15,9 +15,10 @@
 //   energy_b = nanmean over the pairs, +inf if that is NaN                                (:196-198)
 //
 // The stack is the reference's (X, Y, N) layout flattened to (P, N): a pixel's N samples are adjacent.
-// Launch geometry: grid = (pixel chunks, pairs, candidates): every workgroup reduces one pair of one candidate
-// over one pixel chunk, so even the reference's default few-hundred-pixel stacks fill the chip with
-// pairs x population workgroups (the reference evaluates one candidate at a time on the host). The sums are
+// Two launch geometries (chosen in hm_linearity_energy): pair-major, grid = (pixel chunks, pairs, candidates), every
+// workgroup reduces one pair of one candidate over one pixel chunk (any N; a lone candidate still fills the chip
+// with pairs x chunks workgroups); pixel-major for N <= 8, grid = (pixel chunks, candidates), all pairs of a pixel
+// from registers (see k_energy_pixel). The reference evaluates one candidate at a time on the host. The sums are
 // formed in a fixed order (lane-strided, shuffle tree, chunk order), so results are reproducible run to run;
 // they differ from NumPy's pairwise summation in the last bits (tests: 1e-12 relative).
 #include "hm_common.h"
