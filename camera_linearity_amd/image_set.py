@@ -16,7 +16,6 @@ target/original exposure and leaves the source's features untouched; J - works o
 """
 from __future__ import annotations
 
-import copy
 import re
 from pathlib import Path
 from typing import Dict, List, Optional

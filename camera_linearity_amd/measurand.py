@@ -23,7 +23,6 @@ use torch / NumPy on the same tensors so that the class surface is complete.
 """
 from __future__ import annotations
 
-import copy
 import math
 from typing import List, Optional, Union
 

@@ -19,7 +19,6 @@ import numpy as np
 import torch
 
 from . import engine
-from . import settings as gs
 
 FRAMES_PER_LAUNCH = 32      # = HM_MAX_FRAMES: state traffic per element-frame = 32 / 32 = 1 byte with std (measured best)
 

@@ -21,7 +21,7 @@ the reference so that results agree to the last few ulps.
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 

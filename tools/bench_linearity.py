@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""ExposureSeries.process_linearity end to end on a device-resident series: 7 linearized 4096 x 4096 x 3
+float64 frames (+ std), all exposure pairs with ratio >= 0.1. Prints the time per call and per pair."""
+import pathlib
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from camera_linearity_amd.exposure_series import ExposureSeries  # noqa: E402
+from camera_linearity_amd.image_set import ImageSet  # noqa: E402
+from camera_linearity_amd.measurand import HipMeasurand  # noqa: E402
+from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf  # noqa: E402
+from camera_linearity_amd import engine  # noqa: E402
+
+dev = torch.device("cuda:0")
+n, H, W = 7, 4096, 4096
+frames, stds, t = synthetic_stack_device(7, n, H, W, device=dev, with_std=True)
+icrf, diff = synthetic_icrf()
+for use_std in (False, True):
+    sets = []
+    for f, s, ti in zip(frames, stds, t):
+        val, sd = engine.linearize(f, s if use_std else None, icrf, diff if use_std else None)
+        sets.append(ImageSet(measurand=HipMeasurand(val, sd), features={"exposure": float(ti), "illumination": "bf", "magnification": "5x", "subject": "x"}))
+    series = ExposureSeries(input_image_sets=sets)
+    series.initialize_exposure_pairs()
+    npairs = len(series.exposure_pairs)
+    for rep in range(3):
+        # thresholds are applied in place: re-linearize cheaply is not needed for timing (NaNs stay NaNs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        series.process_linearity(icrf, linearity_limit=5, use_std=use_std)
+        ab, rel = series.collect_exposure_pair_stats()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    E = H * W * 3
+    bytes_pairwise = npairs * 2 * (4 if use_std else 2) * 8 * E        # two passes over 2 (4) arrays per pair
+    print(f"use_std={use_std}: {npairs} pairs, {dt * 1e3:.1f} ms per call, {dt / npairs * 1e3:.2f} ms per pair, "
+          f"{bytes_pairwise / dt / 1e12:.2f} TB/s of pair-wise traffic", flush=True)
+    del sets, series

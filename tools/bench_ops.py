@@ -7,7 +7,6 @@ import pathlib
 import statistics
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))

@@ -6,7 +6,6 @@ import pathlib
 import sys
 import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))

@@ -1,4 +1,4 @@
-import csv, glob, sys, re, statistics, subprocess
+import csv, glob, sys, re, statistics
 csv.field_size_limit(1<<30)
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/labprof'
 data = {}
