@@ -101,6 +101,9 @@ def main():
     if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                       # --force-dist without a launcher: a one-rank group
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k_, v_)
         if a.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
