@@ -108,6 +108,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=a.dist_backend)
+        # the first collective creates the RCCL communicator (hundreds of ms during which the GPU idles and drops its
+        # clock): pay for it here, not inside the barrier that opens the timed region
+        dist.barrier()
+        torch.cuda.synchronize()
 
     from camera_linearity_amd import engine
     from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
