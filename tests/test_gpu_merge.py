@@ -504,3 +504,79 @@ def test_merge_special_values(eng):
     close(std[ok], ref["std"][ok], STD_RTOL)
     close(val, ref["val"], VAL_RTOL)
     assert (val[:, 0] == 0).all()
+
+
+def test_merge_randomised_configurations(eng):
+    """120 seeded random configurations (frame count 1..32, ragged sizes, C in 1..4, with / without std, dark maps with
+    3x3 / 5x5 medians, flat field, sum-of-weights output, row tiles with halo) against the oracle."""
+    master = np.random.default_rng(2024)
+    for case in range(120):
+        rng = np.random.default_rng(master.integers(0, 2 ** 31))
+        n = int(rng.choice([1, 2, 3, 5, 7, 9, 15, 16, 17, 23, 32]))
+        C = int(rng.choice([3, 3, 3, 1, 2, 4]))
+        h, w = int(rng.integers(6, 48)), int(rng.integers(5, 70))
+        with_std = bool(rng.integers(0, 2))
+        use_hot = bool(rng.integers(0, 2))
+        use_flat = bool(rng.integers(0, 2))
+        k = int(rng.choice([3, 5]))
+        frames, stds, t = orc.synthetic_stack(int(rng.integers(0, 10 ** 6)), n, h, w, c=C, with_std=with_std)
+        icrf = np.stack([np.linspace(0, 1, 256) ** (1.4 + 0.3 * c) for c in range(C)], axis=1)
+        diff = orc.icrf_derivative(icrf)
+        thr = 0.05
+        darks_dn = None
+        if use_hot:
+            darks_dn = []
+            for i in range(n):
+                if rng.random() < 0.3:
+                    darks_dn.append(None)
+                else:
+                    d = (rng.random((h, w, C)) < 0.03).astype(np.uint8) * rng.integers(20, 255, (h, w, C)).astype(np.uint8)
+                    darks_dn.append(d)
+        flat = rng.integers(150, 240, (h, w, C)).astype(np.uint8) if use_flat else None
+        flat_std = np.full((h, w, C), 0.002) + 0.001 * rng.random((h, w, C)) if use_flat else None
+        ff_mean = list(0.7 + 0.1 * rng.random(C)) if use_flat else None
+        ff_std_mean = list(0.002 + 0.001 * rng.random(C)) if use_flat else None
+        ref = orc.merge(frames, t, icrf, diff if with_std else None, stds=stds,
+                        darks=None if darks_dn is None else [None if d is None else orc.unit_from_u8(d) for d in darks_dn],
+                        dark_threshold=thr, median_k=k,
+                        flat=orc.unit_from_u8(flat) if (use_flat and with_std) else None, flat_std=flat_std if with_std else None,
+                        ff_mean=np.array(ff_mean) if (use_flat and with_std) else None,
+                        ff_std_mean=np.array(ff_std_mean) if (use_flat and with_std) else None)
+        if use_flat and not with_std:                     # val-only flat field = measurand.py:602 alone
+            ref["val_ff"] = (ref["val"] / orc.unit_from_u8(flat)) * np.array(ff_mean)
+        kw = {}
+        if use_hot:
+            kw.update(darks=[None if d is None else dev(d) for d in darks_dn], dark_min=[eng.dark_min_dn(1.0, thr)] * n, median_k=k)
+        if use_flat:
+            kw.update(flat=dev(flat), ff_mean=ff_mean)
+            if with_std:
+                kw.update(flat_std=dev(flat_std), ff_std_mean=ff_std_mean)
+        fr = [dev(f) for f in frames]
+        sd = [dev(s) for s in stds] if with_std else None
+        out = eng.merge(fr, t, icrf, diff if with_std else None, sd, want_sum_w=True, **kw)
+        tag = f"case {case}: n={n} C={C} {h}x{w} std={with_std} hot={use_hot} flat={use_flat} k={k}"
+        want_val = ref["val_ff"] if use_flat else ref["val"]
+        np.testing.assert_allclose(host(out["val"]), want_val, rtol=VAL_RTOL, atol=0, err_msg=tag)
+        np.testing.assert_allclose(host(out["sum_w"]), ref["S"], rtol=1e-13, atol=0, err_msg=tag)
+        if with_std:
+            np.testing.assert_allclose(host(out["std"]), ref["std_ff"] if use_flat else ref["std"], rtol=STD_RTOL, atol=0, err_msg=tag)
+        # the same image as two row tiles with the median halo: bit-identical to the whole-image result
+        if h >= 8:
+            cut = int(rng.integers(2, h - 2))
+            r = k // 2
+            parts = []
+            for (r0, r1) in ((0, cut), (cut, h)):
+                b0, b1 = max(0, r0 - r), min(h, r1 + r)
+                kw_t = {}
+                if use_hot:
+                    kw_t.update(darks=[None if d is None else dev(d[b0:b1]) for d in darks_dn], dark_min=[eng.dark_min_dn(1.0, thr)] * n, median_k=k)
+                if use_flat:
+                    kw_t.update(flat=dev(flat[r0:r1]), ff_mean=ff_mean)
+                    if with_std:
+                        kw_t.update(flat_std=dev(flat_std[r0:r1]), ff_std_mean=ff_std_mean)
+                o = eng.merge([dev(f[b0:b1]) for f in frames], t, icrf, diff if with_std else None,
+                              [dev(s[b0:b1]) for s in stds] if with_std else None, height=h, row0=r0, rows=r1 - r0, buf_row0=b0, **kw_t)
+                parts.append(o)
+            whole = host(out["val"])
+            tiled = np.concatenate([host(p["val"]) for p in parts], axis=0)
+            assert np.array_equal(whole, tiled), tag + " (row tiles)"
