@@ -140,30 +140,97 @@ __global__ __launch_bounds__(256) void k_roi_final(const double* __restrict__ pa
 // ---- normalize_by_map ----
 struct FFMeans { double m[HM_MAX_CHANNELS]; double s[HM_MAX_CHANNELS]; };
 
+// one element of normalize_by_map, operation for operation (measurand.py:585-602)
+__device__ __forceinline__ void normalize_one(double v, double s0, double F, double sF, double m, double s, bool with_std,
+                                              double& ov, double& os) {
+    if (with_std) {
+        const double F2 = F * F;
+        double u_acq = (s0 * s0) / F2;        // measurand.py:586-587
+        u_acq *= m * m;
+        double u_ff = (v * v) / (F2 * F2);    // :590-592
+        u_ff *= sF * sF;
+        u_ff *= m * m;
+        double u_ffm = (v * v) / F2;          // :595-596
+        u_ffm *= s * s;
+        os = sqrt(u_acq + u_ff + u_ffm);      // :599
+    }
+    ov = (v / F) * m;                         // :602
+}
+
+__device__ __forceinline__ double pick(const double (&a)[HM_MAX_CHANNELS], uint32_t c) {      // no per-lane kernarg indexing
+    double r = a[0];
+#pragma unroll
+    for (int k = 1; k < HM_MAX_CHANNELS; ++k) r = (c == static_cast<uint32_t>(k)) ? a[k] : r;
+    return r;
+}
+
+// two elements per lane: 16-byte accesses on every float64 stream (1 KB contiguous per wave instruction), one ushort for a
+// uint8 flat; the channel of the lane's first element is a running counter along the grid-stride loop.
 __global__ __launch_bounds__(256) void k_normalize(const double* __restrict__ val, const double* __restrict__ sd,
                                                    const uint8_t* __restrict__ flat_u8, const double* __restrict__ flat_f64,
                                                    const double* __restrict__ flat_std, const FFMeans ff,
                                                    double* __restrict__ out_val, double* __restrict__ out_std,
                                                    int64_t n, int C) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const int c = static_cast<int>(e % C);
-        const double F = flat_u8 ? static_cast<double>(flat_u8[e]) / 255.0 : flat_f64[e];
-        const double m = ff.m[c];
-        const double v = val[e];
-        if (out_std) {
-            const double s0 = sd[e], sF = flat_std[e], s = ff.s[c];
-            const double F2 = F * F;
-            double u_acq = (s0 * s0) / F2;        // measurand.py:586-587
-            u_acq *= m * m;
-            double u_ff = (v * v) / (F2 * F2);    // :590-592
-            u_ff *= sF * sF;
-            u_ff *= m * m;
-            double u_ffm = (v * v) / F2;          // :595-596
-            u_ffm *= s * s;
-            out_std[e] = sqrt(u_acq + u_ff + u_ffm);   // :599
+    const int64_t units = n / 2;
+    const bool with_std = out_std != nullptr;
+    const bool vec_ok = aligned_dev(val, 16) && aligned_dev(out_val, 16) && (!flat_u8 || aligned_dev(flat_u8, 2)) &&
+                        (!flat_f64 || aligned_dev(flat_f64, 16)) &&
+                        (!with_std || (aligned_dev(sd, 16) && aligned_dev(flat_std, 16) && aligned_dev(out_std, 16)));
+    const uint32_t uC = static_cast<uint32_t>(C);
+    const int64_t u0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint32_t c0 = static_cast<uint32_t>((2 * u0) % C);
+    const uint32_t cstep = static_cast<uint32_t>((2 * stride) % C);
+    for (int64_t u = u0; u < units; u += stride) {
+        const int64_t e = 2 * u;
+        const uint32_t c1 = c0 + 1u == uC ? 0u : c0 + 1u;
+        double v[2], s0[2] = {0.0, 0.0}, F[2], sF[2] = {0.0, 0.0};
+        if (vec_ok) {
+            const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(val + e));
+            v[0] = a.x; v[1] = a.y;
+            if (flat_u8) {
+                const uint32_t r = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(flat_u8 + e));
+                F[0] = static_cast<double>(r & 255u) / 255.0; F[1] = static_cast<double>(r >> 8) / 255.0;
+            } else {
+                const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(flat_f64 + e));
+                F[0] = f.x; F[1] = f.y;
+            }
+            if (with_std) {
+                const f64x2 b = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sd + e));
+                const f64x2 g = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(flat_std + e));
+                s0[0] = b.x; s0[1] = b.y; sF[0] = g.x; sF[1] = g.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                v[j] = val[e + j];
+                F[j] = flat_u8 ? static_cast<double>(flat_u8[e + j]) / 255.0 : flat_f64[e + j];
+                if (with_std) { s0[j] = sd[e + j]; sF[j] = flat_std[e + j]; }
+            }
         }
-        out_val[e] = (v / F) * m;                 // :602
+        double ov[2], os[2] = {0.0, 0.0};
+        normalize_one(v[0], s0[0], F[0], sF[0], pick(ff.m, c0), pick(ff.s, c0), with_std, ov[0], os[0]);
+        normalize_one(v[1], s0[1], F[1], sF[1], pick(ff.m, c1), pick(ff.s, c1), with_std, ov[1], os[1]);
+        if (vec_ok) {
+            f64x2 o; o.x = ov[0]; o.y = ov[1];
+            __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(out_val + e));
+            if (with_std) { f64x2 q; q.x = os[0]; q.y = os[1]; __builtin_nontemporal_store(q, reinterpret_cast<f64x2*>(out_std + e)); }
+        } else {
+            out_val[e] = ov[0]; out_val[e + 1] = ov[1];
+            if (with_std) { out_std[e] = os[0]; out_std[e + 1] = os[1]; }
+        }
+        c0 += cstep;
+        if (c0 >= uC) c0 -= uC;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        const int64_t e = n - 1;
+        const uint32_t c = static_cast<uint32_t>(e % C);
+        const double F = flat_u8 ? static_cast<double>(flat_u8[e]) / 255.0 : flat_f64[e];
+        double ov, os = 0.0;
+        normalize_one(val[e], with_std ? sd[e] : 0.0, F, with_std ? flat_std[e] : 0.0, pick(ff.m, c), pick(ff.s, c), with_std, ov, os);
+        out_val[e] = ov;
+        if (with_std) out_std[e] = os;
     }
 }
 
@@ -231,7 +298,7 @@ extern "C" int hm_normalize_by_map(const double* val, const double* std, const u
     if (out_std && (!std || !flat_std || !ff_std_mean)) return HM_EINVAL;
     FFMeans ff{};
     for (int c = 0; c < C; ++c) { ff.m[c] = ff_mean[c]; ff.s[c] = ff_std_mean ? ff_std_mean[c] : 0.0; }
-    hipLaunchKernelGGL(k_normalize, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(k_normalize, dim3(stream_grid((n + 1) / 2, 256, 8)), dim3(256), 0, as_stream(stream),
                        val, std, flat_u8, flat_f64, flat_std, ff, out_val, out_std, n, C);
     return launch_status();
 }

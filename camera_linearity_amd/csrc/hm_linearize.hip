@@ -69,60 +69,82 @@ __global__ __launch_bounds__(256) void k_weight_u8(const uint8_t* __restrict__ d
 }
 
 // ---------------- linearize ----------------
-// LUT in LDS as {g, d} 16-byte entries, index idx * lut_stride + (e % C) * (lut_stride > 1)
-template <bool F64IN>
+// LUT in LDS: {g, d} 16-byte entries with std, plain 8-byte g entries without (half the LDS bytes per gather);
+// index idx * lut_stride + (e % C) * (lut_stride > 1). The channel of a thread's element is carried along the
+// grid-stride loop as a running counter (one add and one conditional subtract per step instead of a 64-bit modulo).
+template <bool STD> struct LinEntry { typedef double type; };
+template <> struct LinEntry<true> { typedef double2 type; };
+template <bool STD> __device__ __forceinline__ typename LinEntry<STD>::type lin_entry(double g, double d);
+template <> __device__ __forceinline__ double lin_entry<false>(double g, double) { return g; }
+template <> __device__ __forceinline__ double2 lin_entry<true>(double g, double d) { return double2{g, d}; }
+__device__ __forceinline__ double lin_g(double e) { return e; }
+__device__ __forceinline__ double lin_g(double2 e) { return e.x; }
+__device__ __forceinline__ double lin_d(double) { return 0.0; }
+__device__ __forceinline__ double lin_d(double2 e) { return e.y; }
+
+template <bool F64IN, bool STD>
 __global__ __launch_bounds__(256) void k_linearize(const void* __restrict__ in, const double* __restrict__ sd,
                                                    const double* __restrict__ icrf, const double* __restrict__ icrf_diff,
                                                    double* __restrict__ out_val, double* __restrict__ out_std,
                                                    uint8_t* __restrict__ out_idx, int64_t n, int C, int lut_stride) {
-    __shared__ double2 t[256 * HM_MAX_CHANNELS];
+    typedef typename LinEntry<STD>::type Entry;
+    __shared__ Entry t[256 * HM_MAX_CHANNELS];
     const int entries = 256 * lut_stride;
-    const bool with_std = sd && icrf_diff && out_std;           // measurand.py:498-500
-    for (int i = threadIdx.x; i < entries; i += blockDim.x) t[i] = double2{icrf[i], with_std ? icrf_diff[i] : 0.0};
+    for (int i = threadIdx.x; i < entries; i += blockDim.x) t[i] = lin_entry<STD>(icrf[i], STD ? icrf_diff[i] : 0.0);
     __syncthreads();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     const bool per_ch = lut_stride > 1;
+    const uint32_t uC = static_cast<uint32_t>(C), ls = static_cast<uint32_t>(lut_stride);
     if (!F64IN) {
         const uint8_t* dn = static_cast<const uint8_t*>(in);
         const int64_t units = n / 2;
-        const bool vec_ok = aligned_dev(dn, 2) && aligned_dev(out_val, 16) && (!with_std || (aligned_dev(sd, 16) && aligned_dev(out_std, 16)));
-        for (int64_t u = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u < units; u += stride) {
+        const bool vec_ok = aligned_dev(dn, 2) && aligned_dev(out_val, 16) && (!STD || (aligned_dev(sd, 16) && aligned_dev(out_std, 16)));
+        const int64_t u0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+        uint32_t c0 = per_ch ? static_cast<uint32_t>((2 * u0) % C) : 0u;               // channel of element 2u
+        const uint32_t cstep = per_ch ? static_cast<uint32_t>((2 * stride) % C) : 0u;
+        for (int64_t u = u0; u < units; u += stride) {
             const int64_t e0 = 2 * u;
             const uint32_t r = vec_ok ? static_cast<uint32_t>(__builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(dn + e0)))
                                       : (dn[e0] | (static_cast<uint32_t>(dn[e0 + 1]) << 8));
-            const int c0 = per_ch ? static_cast<int>(e0 % C) : 0;
-            const int c1 = per_ch ? (c0 + 1 == C ? 0 : c0 + 1) : 0;
-            const double2 g0 = t[(r & 255u) * lut_stride + c0], g1 = t[(r >> 8) * lut_stride + c1];
+            const uint32_t c1 = per_ch ? (c0 + 1u == uC ? 0u : c0 + 1u) : 0u;
+            const Entry g0 = t[(r & 255u) * ls + c0], g1 = t[(r >> 8) * ls + c1];
             double s0 = 0.0, s1 = 0.0;
-            if (with_std) {
+            if (STD) {
                 if (vec_ok) { const f64x2 sv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sd + e0)); s0 = sv.x; s1 = sv.y; }
                 else { s0 = sd[e0]; s1 = sd[e0 + 1]; }
-                s0 = g0.y * s0; s1 = g1.y * s1;                                          // measurand.py:512
+                s0 = lin_d(g0) * s0; s1 = lin_d(g1) * s1;                                // measurand.py:512
             }
             if (vec_ok) {
-                f64x2 v; v.x = g0.x; v.y = g1.x;
+                f64x2 v; v.x = lin_g(g0); v.y = lin_g(g1);
                 __builtin_nontemporal_store(v, reinterpret_cast<f64x2*>(out_val + e0));
-                if (with_std) { f64x2 q; q.x = s0; q.y = s1; __builtin_nontemporal_store(q, reinterpret_cast<f64x2*>(out_std + e0)); }
+                if (STD) { f64x2 q; q.x = s0; q.y = s1; __builtin_nontemporal_store(q, reinterpret_cast<f64x2*>(out_std + e0)); }
             } else {
-                out_val[e0] = g0.x; out_val[e0 + 1] = g1.x;
-                if (with_std) { out_std[e0] = s0; out_std[e0 + 1] = s1; }
+                out_val[e0] = lin_g(g0); out_val[e0 + 1] = lin_g(g1);
+                if (STD) { out_std[e0] = s0; out_std[e0 + 1] = s1; }
             }
+            c0 += cstep;
+            if (c0 >= uC) c0 -= uC;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
             const int64_t e = n - 1;
-            const double2 gd = t[dn[e] * lut_stride + (per_ch ? static_cast<int>(e % C) : 0)];
-            out_val[e] = gd.x;
-            if (with_std) out_std[e] = gd.y * sd[e];
+            const Entry gd = t[dn[e] * ls + (per_ch ? static_cast<uint32_t>(e % C) : 0u)];
+            out_val[e] = lin_g(gd);
+            if (STD) out_std[e] = lin_d(gd) * sd[e];
         }
     } else {
         const double* v = static_cast<const double*>(in);
-        for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int64_t e_0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+        uint32_t c = per_ch ? static_cast<uint32_t>(e_0 % C) : 0u;
+        const uint32_t cstep = per_ch ? static_cast<uint32_t>(stride % C) : 0u;
+        for (int64_t e = e_0; e < n; e += stride) {
             // around(val * MAX_DN).astype(uint8): round half to even, then wrap (measurand.py:503)
             const uint32_t k = static_cast<uint32_t>(static_cast<int64_t>(rint(v[e] * 255.0))) & 255u;
-            const double2 gd = t[k * lut_stride + (per_ch ? static_cast<int>(e % C) : 0)];
-            out_val[e] = gd.x;
-            if (with_std) out_std[e] = gd.y * sd[e];
+            const Entry gd = t[k * ls + c];
+            out_val[e] = lin_g(gd);
+            if (STD) out_std[e] = lin_d(gd) * sd[e];
             if (out_idx) out_idx[e] = static_cast<uint8_t>(k);
+            c += cstep;
+            if (c >= uC) c -= uC;
         }
     }
 }
@@ -165,12 +187,12 @@ static int linearize_common(bool f64in, const void* in, const double* sd, const 
     if (!aligned(out_val, 8) || (out_std && !aligned(out_std, 8)) || (sd && !aligned(sd, 8)) || (f64in && !aligned(in, 8)))
         return HM_EALIGN;
     const unsigned grid = stream_grid(f64in ? n : (n + 1) / 2, 256, 8);
-    if (f64in)
-        hipLaunchKernelGGL(k_linearize<true>, dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff,
-                           out_val, out_std, out_idx, n, C, lut_stride);
-    else
-        hipLaunchKernelGGL(k_linearize<false>, dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff,
-                           out_val, out_std, out_idx, n, C, lut_stride);
+    const bool with_std = sd && icrf_diff && out_std;                       // measurand.py:498-500
+#define HM_LIN(F, S) hipLaunchKernelGGL((k_linearize<F, S>), dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff, \
+                                        out_val, out_std, out_idx, n, C, lut_stride)
+    if (f64in) { if (with_std) HM_LIN(true, true); else HM_LIN(true, false); }
+    else       { if (with_std) HM_LIN(false, true); else HM_LIN(false, false); }
+#undef HM_LIN
     return launch_status();
 }
 

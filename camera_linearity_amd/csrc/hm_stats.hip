@@ -12,17 +12,39 @@ namespace hm {
 
 struct ChanLimits { double lo[HM_MAX_CHANNELS]; double hi[HM_MAX_CHANNELS]; };
 
+// In place; two elements per lane (16-byte loads; a store only where something changes - thresholds usually clip a
+// minority), running channel counter.
 __global__ __launch_bounds__(256) void k_thresholds(double* __restrict__ val, double* __restrict__ sd, const ChanLimits lim,
                                                     int64_t n, int C) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const int c = static_cast<int>(e % C);
+    const int64_t units = n / 2;
+    const bool vec_ok = aligned_dev(val, 16) && (!sd || aligned_dev(sd, 16));
+    const uint32_t uC = static_cast<uint32_t>(C);
+    const int64_t u0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    uint32_t c0 = static_cast<uint32_t>((2 * u0) % C);
+    const uint32_t cstep = static_cast<uint32_t>((2 * stride) % C);
+    auto lo_of = [&](uint32_t c) { double r = lim.lo[0]; for (int k = 1; k < HM_MAX_CHANNELS; ++k) r = c == static_cast<uint32_t>(k) ? lim.lo[k] : r; return r; };
+    auto hi_of = [&](uint32_t c) { double r = lim.hi[0]; for (int k = 1; k < HM_MAX_CHANNELS; ++k) r = c == static_cast<uint32_t>(k) ? lim.hi[k] : r; return r; };
+    for (int64_t u = u0; u < units; u += stride) {
+        const int64_t e = 2 * u;
+        const uint32_t c1 = c0 + 1u == uC ? 0u : c0 + 1u;
+        double v0, v1;
+        if (vec_ok) { const f64x2 a = *reinterpret_cast<const f64x2*>(val + e); v0 = a.x; v1 = a.y; }
+        else { v0 = val[e]; v1 = val[e + 1]; }
+        const bool k0 = (v0 < lo_of(c0)) || (v0 > hi_of(c0));           // measurand.py:418 (NaN compares false: stays NaN)
+        const bool k1 = (v1 < lo_of(c1)) || (v1 > hi_of(c1));
+        if (k0) { val[e] = nan; if (sd) sd[e] = nan; }
+        if (k1) { val[e + 1] = nan; if (sd) sd[e + 1] = nan; }
+        c0 += cstep;
+        if (c0 >= uC) c0 -= uC;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        const int64_t e = n - 1;
+        const uint32_t c = static_cast<uint32_t>(e % C);
         const double v = val[e];
-        if ((v < lim.lo[c]) | (v > lim.hi[c])) {           // measurand.py:418 (NaN compares false: stays NaN)
-            val[e] = nan;
-            if (sd) sd[e] = nan;
-        }
+        if ((v < lo_of(c)) || (v > hi_of(c))) { val[e] = nan; if (sd) sd[e] = nan; }
     }
 }
 
@@ -395,7 +417,7 @@ extern "C" int hm_apply_thresholds(double* val, double* std, const double* lower
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
     ChanLimits lim{};
     for (int c = 0; c < C; ++c) { lim.lo[c] = lower[c]; lim.hi[c] = upper[c]; }
-    hipLaunchKernelGGL(k_thresholds, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), val, std, lim, n, C);
+    hipLaunchKernelGGL(k_thresholds, dim3(stream_grid((n + 1) / 2, 256, 8)), dim3(256), 0, as_stream(stream), val, std, lim, n, C);
     return launch_status();
 }
 
