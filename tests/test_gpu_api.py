@@ -276,3 +276,25 @@ def test_exposure_pairs_and_linearity_stats():
                     assert f[key] is None
                 else:
                     np.testing.assert_allclose(f[key].cpu().numpy(), u[key].cpu().numpy(), rtol=1e-13)
+
+
+def test_c_abi_example_from_plain_c(tmp_path):
+    """The boundary is a C ABI: examples/merge_c_abi.c (C11, gcc, HIP runtime only - no Python, no torch) links
+    libhdrmerge.so, merges a stack with hm_merge and checks it against its own host loop."""
+    import pathlib
+    import shutil
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    root = pathlib.Path(__file__).resolve().parent.parent
+    lib = root / "camera_linearity_amd" / "lib"
+    exe = tmp_path / "merge_c_abi"
+    cmd = ["gcc", "-std=c11", "-O2", "-D__HIP_PLATFORM_AMD__", str(root / "examples" / "merge_c_abi.c"), f"-I{root / 'include'}",
+           "-I/opt/rocm/include", f"-L{lib}", "-lhdrmerge", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}",
+           "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI merge OK" in r.stdout
