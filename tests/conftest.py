@@ -15,6 +15,13 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / "tests" / "golden"
 
+try:        # property tests draw the same examples on every run (no example database, no per-example deadline)
+    from hypothesis import settings as _hyp_settings
+    _hyp_settings.register_profile("deterministic", derandomize=True, deadline=None, database=None)
+    _hyp_settings.load_profile("deterministic")
+except ImportError:      # pragma: no cover
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
