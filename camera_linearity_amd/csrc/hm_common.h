@@ -31,6 +31,14 @@ inline unsigned stream_grid(int64_t work_items, int block, int blocks_per_cu) {
     return static_cast<unsigned>(need < cap ? need : cap);
 }
 
+// Gaussian weight of the merge, measurand.py:615: w = e ** (-30 (v - 0.5)^2) with dv = v - 0.5. One definition for every
+// kernel that evaluates it analytically (float64 frames), so they agree bit for bit.
+#ifdef HM_FAKE_EXP          /* timing experiment only: removes the cost of exp() */
+__device__ __forceinline__ double gauss_weight(double dv) { return 1.0 + -30.0 * (dv * dv); }
+#else
+__device__ __forceinline__ double gauss_weight(double dv) { return exp(-30.0 * (dv * dv)); }
+#endif
+
 // scipy.ndimage 'reflect' (d c b a | a b c d) index fold, valid for any offset
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {
     while (i < 0 || i >= n) {

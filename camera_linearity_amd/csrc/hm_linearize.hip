@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_weight_f64(const double* __restrict__ v
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
         const double d = v[e] - 0.5;
-        const double y = exp(-30.0 * (d * d));          // np.e ** (-30 (v - 0.5)^2), measurand.py:615
+        const double y = gauss_weight(d);          // np.e ** (-30 (v - 0.5)^2), measurand.py:615
         if (w) w[e] = y;
         if (dw) dw[e] = (-60.0 * d) * y;                // -2 * 30 * (v - 0.5) * y, measurand.py:616
     }

@@ -121,7 +121,7 @@ __device__ __forceinline__ void merge_one_element(const MergeK& a, const double*
         double w;
         if (F64IN) {
             const double dv = value_f64(i, hot) - 0.5;
-            w = exp(-30.0 * (dv * dv));                                 // measurand.py:615
+            w = gauss_weight(dv);                                 // measurand.py:615
         } else {
             w = t_w[value_u8(i, hot)];
         }
@@ -140,7 +140,7 @@ __device__ __forceinline__ void merge_one_element(const MergeK& a, const double*
         if (F64IN) {
             const double v = value_f64(i, hot);
             const double dv = v - 0.5;
-            w = exp(-30.0 * (dv * dv));
+            w = gauss_weight(dv);
             dw = (-60.0 * dv) * w;                                      // measurand.py:616
             idx = static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;   // measurand.py:503
         } else {
@@ -286,7 +286,7 @@ __device__ __forceinline__ void fixup_element(const MergeK& a, const double* t_w
     if (owner) {
         if (F64IN) {
             const double dv = v - 0.5;
-            w = exp(-30.0 * (dv * dv));
+            w = gauss_weight(dv);
             dw = (-60.0 * dv) * w;
             idx = static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;
         } else {
@@ -854,23 +854,25 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// merge_f64_loop: float64 frames (the reference's 64-bit mode, image_set.py:225 / frames saved by save_64bit) with the
+// merge_f64_val / merge_f64_std (body: merge_f64_body): float64 frames (the reference's 64-bit mode, image_set.py:225 / frames saved by save_64bit) with the
 // streaming decomposition of merge_u8_loop: lane l owns elements 2l, 2l+1 of a 128-element group, every frame / std /
 // output access is one 16-byte load or store per lane (1 KB contiguous per wave instruction). The weight is evaluated
 // analytically (measurand.py:615-616) and the LUT index is computed (round-half-even, wrap, :503), exactly as
 // merge_generic does; val-only needs one pass (S and the numerator accumulate together), std needs S first and
-// re-evaluates the weights in its second pass (frames re-read from cache; keeping the pass-1 weights of small
-// stacks in registers instead was measured slower: 139 VGPRs, 1 813 vs 1 704 us on 7 x 4096 x 4096 x 3). merge_generic evaluated exp() twice per
+// re-evaluates the weights in its second pass. Stacks of up to 8 frames keep the frame VALUES in registers between
+// the passes; larger ones re-read them (not the weights: with exp() stubbed out the kernel is 1.5 % faster, it is
+// bound by memory traffic, and the re-read misses the caches). merge_generic evaluated exp() twice per
 // element-frame even for val-only and moved 8-byte pieces: 1 307 -> see DESIGN.md 8 for the numbers.
 // ------------------------------------------------------------------------------------------------
 constexpr int kF64Chunk = 4;
+constexpr int kF64Keep = 8;        // std mode: stacks up to this size keep their frame values in registers between the passes
 
 __device__ __forceinline__ uint32_t lut_index_f64(double v) {
     return static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;          // measurand.py:503
 }
 
 template <int C, bool STD, bool FLAT, bool SUMW>
-__global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
+__device__ __forceinline__ void merge_f64_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
                         for (int j = 0; j < 2; ++j) {
                             const double x = j == 0 ? v[k].x : v[k].y;
                             const double dv = x - 0.5;
-                            const double w = exp(-30.0 * (dv * dv));                            // measurand.py:615
+                            const double w = gauss_weight(dv);                            // measurand.py:615
                             const double gg = t_gd[lut_index_f64(x) * C + cs[j]].x;
                             const double wg = w * gg;
                             if (i0 + k == 0) { S[j] = w; acc[j] = wg * it; }
@@ -962,7 +964,40 @@ __global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
                 if (i == 0) { acc[j] = wg * it; var[j] = term * term; }
                 else { acc[j] = fma(wg, it, acc[j]); var[j] = fma(term, term, var[j]); }
             };
-            {
+            if (N <= kF64Keep) {
+                // small stacks: the frame values stay in registers between the passes (re-reading them misses the
+                // caches - 7 KB per wave-iteration, 20 waves per CU - and costs 56 B/element of extra traffic);
+                // the weight is re-evaluated, exp() is not what bounds this kernel
+                f64x2 v[kF64Keep];
+#pragma unroll
+                for (int i = 0; i < kF64Keep; ++i)
+                    if (i < N) v[i] = ld2(static_cast<const double*>(a.frame[i]) + ibase);
+#pragma unroll
+                for (int i = 0; i < kF64Keep; ++i) {
+                    if (i < N) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const double w = gauss_weight((j == 0 ? v[i].x : v[i].y) - 0.5);
+                            if (i == 0) S[j] = w; else S[j] += w;
+                        }
+                        HM_PIN(S[0]); HM_PIN(S[1]);                 // one frame's exp() pair at a time: their temporaries,
+                        __builtin_amdgcn_sched_barrier(0);          // interleaved across frames, are the register peak
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { invS[j] = 1.0 / S[j]; invS2[j] = 1.0 / (S[j] * S[j]); }
+#pragma unroll
+                for (int i = 0; i < kF64Keep; ++i) {
+                    if (i < N) {
+                        const f64x2 sdv = ld2(a.sd[i] + ibase);
+                        const double it = a.inv_t[i];
+                        pass2(i, 0, v[i].x, gauss_weight(v[i].x - 0.5), sdv.x, it);
+                        pass2(i, 1, v[i].y, gauss_weight(v[i].y - 0.5), sdv.y, it);
+                        HM_PIN(acc[0]); HM_PIN(acc[1]); HM_PIN(var[0]); HM_PIN(var[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
                 for (int i0 = 0; i0 < N; i0 += kF64Chunk) {                                    // pass 1: S
                     f64x2 v[kF64Chunk];
 #pragma unroll
@@ -974,7 +1009,7 @@ __global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 const double dv = (j == 0 ? v[k].x : v[k].y) - 0.5;
-                                const double w = exp(-30.0 * (dv * dv));
+                                const double w = gauss_weight(dv);
                                 if (i0 + k == 0) S[j] = w; else S[j] += w;
                             }
                         }
@@ -999,7 +1034,7 @@ __global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
                             for (int j = 0; j < 2; ++j) {
                                 const double x = j == 0 ? v[k].x : v[k].y;
                                 const double dv = x - 0.5;
-                                pass2(i0 + k, j, x, exp(-30.0 * (dv * dv)), j == 0 ? sdv[k].x : sdv[k].y, it);
+                                pass2(i0 + k, j, x, gauss_weight(dv), j == 0 ? sdv[k].x : sdv[k].y, it);
                             }
                         }
                     }
@@ -1017,6 +1052,24 @@ __global__ __launch_bounds__(256) void merge_f64_loop(const MergeK a) {
             store2(a.out_std + sbase, lane16, so[0], so[1]);
         }
     }
+}
+
+// The two entry points differ in the occupancy the register allocator is asked for (A/B on one box, tools/ab3.sh):
+// val-only runs best when it may use up to 168 VGPRs (3 waves/SIMD: more loads in flight per wave, 665 -> 599 us on
+// 7 x 4096 x 4096 x 3), the std kernel at 4 waves/SIMD (127 VGPRs + 20 B scratch, 1 382 -> 1 343 us).
+#ifndef HM_F64_VAL_WAVES
+#define HM_F64_VAL_WAVES 3
+#endif
+#ifndef HM_F64_STD_WAVES
+#define HM_F64_STD_WAVES 4
+#endif
+template <int C, bool FLAT, bool SUMW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HM_F64_VAL_WAVES, HM_F64_VAL_WAVES))) void merge_f64_val(const MergeK a) {
+    merge_f64_body<C, false, FLAT, SUMW>(a);
+}
+template <int C, bool FLAT, bool SUMW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HM_F64_STD_WAVES, HM_F64_STD_WAVES))) void merge_f64_std(const MergeK a) {
+    merge_f64_body<C, true, FLAT, SUMW>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1163,13 +1216,13 @@ static int launch_f64_c(const MergeK& k, bool with_std, hipStream_t st) {
     const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
     const int lds = 16 * 256 * C + (flat ? 16 * 256 : 0);
     const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
-#define HM_F64(S, F, W) hipLaunchKernelGGL((merge_f64_loop<C, S, F, W>), dim3(grid), dim3(256), lds, st, k)
+#define HM_F64(K, F, W) hipLaunchKernelGGL((K<C, F, W>), dim3(grid), dim3(256), lds, st, k)
     if (with_std) {
-        if (flat && sumw) HM_F64(true, true, true); else if (flat) HM_F64(true, true, false);
-        else if (sumw) HM_F64(true, false, true); else HM_F64(true, false, false);
+        if (flat && sumw) HM_F64(merge_f64_std, true, true); else if (flat) HM_F64(merge_f64_std, true, false);
+        else if (sumw) HM_F64(merge_f64_std, false, true); else HM_F64(merge_f64_std, false, false);
     } else {
-        if (flat && sumw) HM_F64(false, true, true); else if (flat) HM_F64(false, true, false);
-        else if (sumw) HM_F64(false, false, true); else HM_F64(false, false, false);
+        if (flat && sumw) HM_F64(merge_f64_val, true, true); else if (flat) HM_F64(merge_f64_val, true, false);
+        else if (sumw) HM_F64(merge_f64_val, false, true); else HM_F64(merge_f64_val, false, false);
     }
 #undef HM_F64
     return launch_status();
