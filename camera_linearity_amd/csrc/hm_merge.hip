@@ -484,7 +484,7 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #endif
 
 template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
-__global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const MergeK a) {
+__device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int C = 3;
     constexpr uint32_t GROUP = U * kSub;
@@ -676,6 +676,22 @@ __global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const Merge
             __builtin_amdgcn_sched_barrier(0);   // keep one sub-unit's gathers from piling onto the next one's
         }
     }
+}
+
+// Entry points. The std kernel is given an occupancy target of 3 waves/SIMD: with up to 168 VGPRs the scheduler keeps more
+// loads in flight per wave (A/B on one box, tools/ab3.sh: 7 x 4096 x 4096 x 3 + std 716 -> 697 us, + flat field 869 -> 823 us;
+// targets 4 and 5 are slower, the val-only kernel is insensitive).
+#ifndef HM_STD_WAVES
+#define HM_STD_WAVES 3
+#endif
+template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const MergeK a) {
+    static_assert(!STD, "std instantiations go through merge_u8_fast_std");
+    merge_u8_fast_body<NF, U, TAB, false, PREFETCH, FLAT, SUMW, BLOCK>(a);
+}
+template <int NF, int U, int TAB, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HM_STD_WAVES, HM_STD_WAVES))) void merge_u8_fast_std(const MergeK a) {
+    merge_u8_fast_body<NF, U, TAB, true, PREFETCH, FLAT, SUMW, BLOCK>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1119,7 +1135,9 @@ static bool decode_variant(int variant, bool with_std, FastCfg& c) {
 template <int NF, int U, int TAB, bool STD, bool PF, bool FLAT, bool SUMW, int BLOCK>
 static int launch_one(const MergeK& k, hipStream_t st) {
     constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + (FLAT ? 16 * 256 : 0);
-    auto kernel = merge_u8_fast<NF, U, TAB, STD, PF, FLAT, SUMW, BLOCK>;
+    void (*kernel)(const MergeK);
+    if constexpr (STD) kernel = merge_u8_fast_std<NF, U, TAB, PF, FLAT, SUMW, BLOCK>;
+    else kernel = merge_u8_fast<NF, U, TAB, false, PF, FLAT, SUMW, BLOCK>;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
     const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
