@@ -706,7 +706,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HM_STD_WA
 constexpr int kLoopChunk = 8;
 
 template <int C, bool STD, bool FLAT, bool SUMW>
-__global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
+__device__ __forceinline__ void merge_u8_loop_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
@@ -868,6 +868,21 @@ __global__ __launch_bounds__(256) void merge_u8_loop(const MergeK a) {
         }
     }
 }
+
+#ifdef HM_LOOP_VAL_WAVES
+#define HM_LOOP_VAL_ATTR __attribute__((amdgpu_waves_per_eu(HM_LOOP_VAL_WAVES, HM_LOOP_VAL_WAVES)))
+#else
+#define HM_LOOP_VAL_ATTR
+#endif
+#ifdef HM_LOOP_STD_WAVES
+#define HM_LOOP_STD_ATTR __attribute__((amdgpu_waves_per_eu(HM_LOOP_STD_WAVES, HM_LOOP_STD_WAVES)))
+#else
+#define HM_LOOP_STD_ATTR
+#endif
+template <int C, bool FLAT, bool SUMW>
+__global__ __launch_bounds__(256) HM_LOOP_VAL_ATTR void merge_u8_loop(const MergeK a) { merge_u8_loop_body<C, false, FLAT, SUMW>(a); }
+template <int C, bool FLAT, bool SUMW>
+__global__ __launch_bounds__(256) HM_LOOP_STD_ATTR void merge_u8_loop_std(const MergeK a) { merge_u8_loop_body<C, true, FLAT, SUMW>(a); }
 
 // ------------------------------------------------------------------------------------------------
 // merge_f64_val / merge_f64_std (body: merge_f64_body): float64 frames (the reference's 64-bit mode, image_set.py:225 / frames saved by save_64bit) with the
@@ -1217,13 +1232,13 @@ static int launch_loop_c(const MergeK& k, bool with_std, hipStream_t st) {
     const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
     const int lds = (with_std ? 16 * 256 + 16 * 256 * C : 16 * 256 * C) + (flat ? 16 * 256 : 0);
     const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
-#define HM_LOOP(S, F, W) hipLaunchKernelGGL((merge_u8_loop<C, S, F, W>), dim3(grid), dim3(256), lds, st, k)
+#define HM_LOOP(K, F, W) hipLaunchKernelGGL((K<C, F, W>), dim3(grid), dim3(256), lds, st, k)
     if (with_std) {
-        if (flat && sumw) HM_LOOP(true, true, true); else if (flat) HM_LOOP(true, true, false);
-        else if (sumw) HM_LOOP(true, false, true); else HM_LOOP(true, false, false);
+        if (flat && sumw) HM_LOOP(merge_u8_loop_std, true, true); else if (flat) HM_LOOP(merge_u8_loop_std, true, false);
+        else if (sumw) HM_LOOP(merge_u8_loop_std, false, true); else HM_LOOP(merge_u8_loop_std, false, false);
     } else {
-        if (flat && sumw) HM_LOOP(false, true, true); else if (flat) HM_LOOP(false, true, false);
-        else if (sumw) HM_LOOP(false, false, true); else HM_LOOP(false, false, false);
+        if (flat && sumw) HM_LOOP(merge_u8_loop, true, true); else if (flat) HM_LOOP(merge_u8_loop, true, false);
+        else if (sumw) HM_LOOP(merge_u8_loop, false, true); else HM_LOOP(merge_u8_loop, false, false);
     }
 #undef HM_LOOP
     return launch_status();
