@@ -180,10 +180,10 @@ def main():
         rows = min(a.cpu_rows, H)
         ref, dt = cpu_baseline(frames, t, icrf, diff, stds, rows)
         got = plan.outputs["val"][:rows].cpu().numpy()
-        diff = np.abs(got - ref["val"])
+        err = np.abs(got - ref["val"])
         denom = np.abs(ref["val"])
         nz = denom > 0                                   # radiance is exactly 0 where every frame has DN 0 (ICRF[0] = 0)
-        max_rel = float(max(np.max(diff[nz] / denom[nz]) if nz.any() else 0.0, np.max(diff[~nz]) if (~nz).any() else 0.0))
+        max_rel = float(max(np.max(err[nz] / denom[nz]) if nz.any() else 0.0, np.max(err[~nz]) if (~nz).any() else 0.0))
         cpu = {"value": round(rows * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
                "sample": f"rows 0..{rows - 1} of the bench stack ({n}x{rows}x{W}x3, {dt:.1f} s), NumPy oracle, 1 thread of "
                          f"{os.cpu_count()} host cores",
