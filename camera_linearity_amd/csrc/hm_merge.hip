@@ -473,6 +473,9 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #ifndef HM_FB
 #define HM_FB 4
 #endif
+#ifndef HM_STD_FB
+#define HM_STD_FB 2      // std kernel, pass 2: frames per scheduling bundle
+#endif
 #ifndef HM_PIN_NF
 #define HM_PIN_NF 8      // std kernel: above this N, pass 2 re-derives its per-frame addresses (registers)
 #endif
@@ -653,10 +656,10 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
                             var[j] = fma(term, term, var[j]);
                         }
                     }
-                    if ((i & 1) == 1 || i == NF - 1) {
+                    if ((i % HM_STD_FB) == HM_STD_FB - 1 || i == NF - 1) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) { HM_PIN(acc[j]); HM_PIN(var[j]); }
-                        __builtin_amdgcn_sched_barrier(0);   // two frames' std loads + gathers at a time
+                        __builtin_amdgcn_sched_barrier(0);   // HM_STD_FB frames' std loads + gathers at a time
                     }
                 }
                 double val[2], so[2];
