@@ -11,10 +11,13 @@
 // 8-bit frames both the Gaussian weight and the ICRF depend on the DN alone; the 256-entry tables
 // (w, w*g per channel, ...) live in LDS.
 //
-// Kernels:
-//   merge_u8_fast     C == 3, N <= 16 (compile-time), 2-byte-aligned uint8 frames; the bench path.
-//   merge_generic     anything else (float64 frames, other C, N <= 32, tails, unaligned tiles):
-//                     one element per thread, the same operation sequence.
+// Kernels (hm_merge dispatches; all share one operation sequence per output element, so a result does not depend on
+// which kernel or tiling produced it):
+//   merge_u8_fast / merge_u8_fast_std   C == 3, N <= 16 (compile-time), 2-byte-aligned uint8 frames; the bench path.
+//   merge_u8_loop / merge_u8_loop_std   uint8 frames, run-time N (17..32) and C (1..4): same decomposition, frames in chunks.
+//   merge_f64_val / merge_f64_std       float64 frames (64-bit mode): analytic weight, computed LUT index.
+//   merge_generic     anything else (tails shorter than a group, unaligned tiles, forced by variant < 0):
+//                     one element per thread.
 //   merge_fixup_hot   dark-frame hot pixels (~1e-4 of the image): scans the dark maps and recomputes the
 //                     affected output elements with the k x k medians substituted. Keeping the rare,
 //                     divergent, register-hungry median out of the streaming kernels is worth 5x on
