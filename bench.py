@@ -37,6 +37,7 @@ WORKLOADS = {
     "cfg3hot": (7, 4096, 4096, True, "hot"),    # std + dark hot-pixel maps
     "cfg4tile": (15, 1024, 8192, False, False),  # configs[3]: one of 8 row tiles of 15 x 8192 x 8192 x 3
     "cfg4tilestd": (15, 1024, 8192, True, False),  # configs[3] "+std" variant of the same tile
+    "cfg2rand": (7, 4096, 4096, False, False),  # config 2 with uniform-random DNs: the worst case for LDS bank conflicts
     "cfg2f64": (7, 4096, 4096, False, False),   # 64-bit mode (image_set.py:225): float64 frames, analytic weights, computed index
     "cfg3f64std": (7, 4096, 4096, True, False),  # 64-bit mode with std
 }
@@ -120,6 +121,9 @@ def main():
     frames, stds, t = synthetic_stack_device(7 + rank, n, H, W, device=dev, with_std=with_std)
     if "f64" in a.workload:
         frames = [engine.u8_to_unit(f) for f in frames]
+    if a.workload == "cfg2rand":
+        gen = torch.Generator(device=dev).manual_seed(7 + rank)
+        frames = [torch.randint(0, 256, f.shape, dtype=torch.uint8, device=dev, generator=gen) for f in frames]
     icrf, diff = synthetic_icrf()
     kw = {}
     if corr:
