@@ -580,3 +580,50 @@ def test_merge_randomised_configurations(eng):
             whole = host(out["val"])
             tiled = np.concatenate([host(p["val"]) for p in parts], axis=0)
             assert np.array_equal(whole, tiled), tag + " (row tiles)"
+
+
+def test_merge_full_size_properties(eng):
+    """BASELINE config 2 / 3 size (7 x 4096 x 4096 x 3), checked through size-independent properties instead of the oracle:
+    (1) exposure scaling: doubling every exposure halves radiance and uncertainty exactly (power of two, bit-exact);
+    (2) tiling invariance: two row tiles reproduce the whole image bit for bit;
+    (3) kernel invariance: the generic kernel reproduces the streaming kernel bit for bit (checksum of the raw bits);
+    (4) a row band against the oracle (1e-12);
+    (5) constant frames: a stack whose frames all hold one DN merges to ICRF[DN] * sum(w / t) / sum(w) everywhere."""
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf
+    n, H, W = 7, 4096, 4096
+    frames, stds, t = synthetic_stack_device(11, n, H, W, device="cuda", with_std=True)
+    icrf, diff = synthetic_icrf()
+    base = eng.merge(frames, t, icrf, diff, stds)
+    val, std = base["val"], base["std"]
+    # (1)
+    dbl = eng.merge(frames, [2 * x for x in t], icrf, diff, stds)
+    assert torch.equal(dbl["val"], val * 0.5) and torch.equal(dbl["std"], std * 0.5)
+    del dbl
+    # (2)
+    cut = 1777
+    top = eng.merge([f[:cut] for f in frames], t, icrf, diff, [s[:cut] for s in stds], height=H, row0=0, rows=cut, buf_row0=0)
+    bot = eng.merge([f[cut:] for f in frames], t, icrf, diff, [s[cut:] for s in stds], height=H, row0=cut, rows=H - cut, buf_row0=cut)
+    assert torch.equal(top["val"], val[:cut]) and torch.equal(bot["val"], val[cut:])
+    assert torch.equal(top["std"], std[:cut]) and torch.equal(bot["std"], std[cut:])
+    del top, bot
+    # (3)
+    gen = eng.merge(frames, t, icrf, diff, stds, variant=-1)
+    def checksum(x):
+        return int(x.view(torch.int64).sum().item())
+    assert checksum(gen["val"]) == checksum(val) and checksum(gen["std"]) == checksum(std)
+    assert torch.equal(gen["val"], val)
+    del gen
+    # (4)
+    rows = 64
+    ref = orc.merge([f[:rows].cpu().numpy() for f in frames], t, icrf, diff, stds=[s[:rows].cpu().numpy() for s in stds])
+    close(host(val[:rows]), ref["val"], VAL_RTOL)
+    close(host(std[:rows]), ref["std"], STD_RTOL)
+    # (5) val-only, constant frames
+    dn = 97
+    const = [torch.full((H, W, 3), dn, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    out = eng.merge(const, t, icrf)["val"]
+    w = orc.gaussian_weight_lut()[0][dn]
+    expect = np.array([icrf[dn, c] * sum(w / ti for ti in t) / (n * w) for c in range(3)])
+    got = out.reshape(-1, 3)
+    assert bool((got == got[0]).all())
+    np.testing.assert_allclose(host(got[0]), expect, rtol=1e-14)
