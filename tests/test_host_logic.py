@@ -51,6 +51,22 @@ def test_argument_validation_without_device():
     assert nat.lib.hm_linearize_u8(None, None, None, None, None, None, 0, 3, 3, None) == nat.HM_EINVAL
     assert nat.lib.hm_binary_op(9, None, None, None, None, None, None, 1, None, None, None, None) == nat.HM_EINVAL
     assert nat.lib.hm_roi_mean_workspace_bytes() >= 8 * 4
+    # the 8(f) entry points validate before any device work too
+    one = (C.c_void_p * 1)(None)
+    assert nat.lib.hm_welford_update(one, 40, 0, None, None, None, 12, 3, None) == nat.HM_EINVAL          # > HM_MAX_FRAMES
+    assert nat.lib.hm_welford_update(one, 1, 0, None, None, None, 12, 5, None) == nat.HM_ESHAPE           # C > 4
+    assert nat.lib.hm_welford_update(one, 1, 0, None, None, None, 10, 3, None) == nat.HM_ESHAPE           # n_elems % C != 0
+    assert nat.lib.hm_welford_update(one, 0, 0, None, None, None, 12, 3, None) == nat.HM_OK               # nothing to fold
+    assert nat.lib.hm_welford_update(one, 1, 0, None, None, None, 12, 3, None) == nat.HM_EINVAL           # null state / frame
+    assert nat.lib.hm_welford_finalize(None, None, 0, None, None, 12, None) == nat.HM_EINVAL              # count < 1
+    assert nat.lib.hm_welford_algorithmic_bytes(16, 1, 100) == 100 * (16 + 32)
+    t3 = (C.c_double * 3)(1.0, 2.0, 4.0)
+    assert nat.lib.hm_linearity_energy(None, None, t3, None, None, 4, 5, 250, 1, 16, 1, None, None, None, None) == nat.HM_ESHAPE   # one frame
+    assert nat.lib.hm_linearity_energy(None, None, t3, None, None, 4, 5, 300, 1, 16, 3, None, None, None, None) == nat.HM_EINVAL  # limit > 255
+    assert nat.lib.hm_linearity_energy(None, None, t3, None, None, 0, 5, 250, 1, 16, 3, None, None, None, None) == nat.HM_OK      # no candidates
+    assert nat.lib.hm_linearity_energy(None, None, t3, None, None, 4, 5, 250, 1, 16, 3, None, None, None, None) == nat.HM_EINVAL  # null buffers
+    assert nat.lib.hm_linearity_energy_workspace_bytes(1 << 20, 7, 75) == 75 * 21 * 64 * 16
+    assert nat.lib.hm_tiff_lzw_decode(None, 0, None, 0) == nat.HM_EINVAL
     with pytest.raises(ValueError):
         nat.check(nat.HM_ESHAPE)
     with pytest.raises(NotImplementedError):
