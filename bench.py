@@ -73,12 +73,88 @@ def cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads):
     return time.perf_counter() - t0
 
 
+def producer_workload(a, dev):
+    """The SURVEY.md 8(f) rows as bench workloads (one GPU): same timing discipline as the merge (pre-warm, warm-up, K
+    launches between two events) and a cpu_baseline leg = the oracle on a bounded sample. Prints one JSON line."""
+    from camera_linearity_amd import engine, _native as nat
+    steps, warmup = min(a.steps, 50), min(a.warmup, 5)
+    if a.workload == "welford":
+        H, W, K = 4096, 4096, 32
+        g = torch.Generator(device=dev).manual_seed(1)
+        clip = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=dev, generator=g) for _ in range(K)]
+        mean = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+        m2 = torch.zeros_like(mean)
+        launch = lambda: engine.welford_update(clip, 5, mean, m2)                       # noqa: E731
+        alg = int(nat.lib.hm_welford_algorithmic_bytes(K, 1, H * W * 3))
+        units, unit, metric = H * W * K, "Mpix-frames/s", "Welford-folded Mpix-frames/s (mean + M2, 32 frames per launch)"
+        cfg = {"workload": f"{K} uint8 4096x4096x3 frames folded into float64 mean / M2 per launch", "name": "welford"}
+        kernel, bound_note = "k_welford", "FP64 VALU from ~12 frames per launch up (DESIGN.md 4.5); frac is against the HBM roofline"
+    else:
+        X = Y = 1024
+        N, B = 7, 75
+        rng = np.random.default_rng(2)
+        t = 1e-3 * 2.0 ** np.arange(N)
+        dn_h = rng.integers(0, 256, (X, Y, N), dtype=np.uint8)
+        dn = torch.as_tensor(dn_h, device=dev)
+        icrfs = np.linspace(0, 1, 256)[None, :] ** np.linspace(1.2, 3.0, B)[:, None]
+        icrfs[:, -1] = 1.0
+        icrfs_d = torch.as_tensor(icrfs, device=dev)
+        launch = lambda: engine.linearity_energy(dn, None, t, icrfs_d, 5, 250)          # noqa: E731
+        alg = X * Y * N * B                                                              # stack bytes x candidates
+        units, unit, metric = B, "candidates/s", "ICRF-calibration energy evaluations/s (1024x1024x7 stack, 75 candidates per launch)"
+        cfg = {"workload": "energy function of 75 candidate ICRFs on a 1024x1024x7 uint8 channel stack per launch", "name": "energy"}
+        kernel, bound_note = "k_energy_pixel", "FP64 VALU (DESIGN.md 4.5); frac is against the HBM roofline and not the relevant bound"
+    t_end = time.perf_counter() + a.prewarm_s
+    while time.perf_counter() < t_end:
+        launch()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        launch()
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    avg_us = ev0.elapsed_time(ev1) * 1e3 / steps
+    cpu = None
+    if not a.no_cpu_baseline:
+        from oracle import hdr_oracle as orc
+        if a.workload == "welford":
+            sample = [f[:2048].cpu().numpy() for f in clip]
+            c0 = time.perf_counter()
+            orc.welford_state(sample, None, True)
+            dt = time.perf_counter() - c0
+            cpu = {"value": round(2048 * W * K / dt / 1e6, 3), "unit": unit, "cores": 1, "kind": "port",
+                   "sample": f"{K} frames of 2048x{W}x3 ({dt:.1f} s), NumPy oracle, 1 thread"}
+        else:
+            reps = 10
+            c0 = time.perf_counter()
+            for b in range(reps):
+                orc.energy_function(icrfs[b], dn_h, None, 5, 250, t)
+            dt = time.perf_counter() - c0
+            cpu = {"value": round(reps / dt, 4), "unit": unit, "cores": 1, "kind": "port",
+                   "sample": f"{reps} of the 75 candidates on the full 1024x1024x7 stack ({dt:.1f} s), NumPy oracle, 1 thread"}
+    scale_u = 1e6 if unit.startswith("M") else 1.0
+    line = {"metric": metric, "value": round(steps * units / elapsed / scale_u, 2), "unit": unit, "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic", "config": cfg,
+            "roofline": {"bound": "hbm", "achieved": round(alg / avg_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(alg / avg_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2), "note": bound_note},
+            "cpu_baseline": cpu}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["welford", "energy"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N > 1 path on one GPU)")
@@ -114,6 +190,9 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
+    if a.workload in ("welford", "energy"):          # single-GPU workloads with their own line
+        producer_workload(a, dev)
+        return
     from camera_linearity_amd import engine
     from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the SURVEY.md 8(f) rows next to the merge, with the oracle (NumPy restatement of the reference) timed
-beside each on a bounded sample:
+"""Throughput of the SURVEY.md 8(f) rows next to the merge (GPU side only; the CPU baselines of these rows are the
+`cpu_baseline` legs of `bench.py --workload welford` / `--workload energy`):
   - Welford mean / M2 producer (hm_welford_update): 4096 x 4096 x 3 frames, K frames per launch, against its algorithmic
     bytes  E * (K + 32)  [+16 without M2];
   - ICRF-calibration energy function (hm_linearity_energy): one DE generation (75 candidates) per launch at the
@@ -17,7 +17,6 @@ import torch
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from camera_linearity_amd import engine, _native as nat  # noqa: E402
-from oracle import hdr_oracle as orc  # noqa: E402   (cpu baseline leg only)
 
 dev = torch.device("cuda:0")
 out = {"welford": [], "energy": []}
@@ -68,13 +67,6 @@ for K, with_m2, lut in ((8, True, None), (16, True, None), (32, True, None), (32
            "frac_of_8TB/s": round(b / us / 1e3 / 8000, 3), "Mpix_frames/s": round(H * W * K / us, 1)}
     out["welford"].append(row)
     print("welford", row, flush=True)
-# CPU: the oracle on a 512 x 512 x 3 crop, 8 frames
-small = [f[:512, :512].cpu().numpy() for f in clip[:8]]
-t0 = time.perf_counter()
-orc.welford_state(small, None, True)
-dt = time.perf_counter() - t0
-out["welford_cpu"] = {"sample": "8 frames 512x512x3", "Mpix_frames/s": round(512 * 512 * 8 / dt / 1e6, 2), "cores": 1}
-print("welford cpu", out["welford_cpu"], flush=True)
 del clip, mean, m2
 
 # ---------------------------------------------------------------- energy function
@@ -93,13 +85,6 @@ for (X, Y, N, B) in ((28, 28, 7, 75), (256, 256, 7, 75), (1024, 1024, 7, 75), (1
         pair_px = X * Y * (N * (N - 1) // 2) * B
         row = {"stack": f"{X}x{Y}x{N}", "candidates": B, "std": with_std, "us_per_launch": round(us, 1),
                "us_per_candidate": round(us / B, 2), "Gpair_px/s": round(pair_px / us / 1e3, 2)}
-        if X <= 256:
-            reps = 3
-            t0 = time.perf_counter()
-            for b in range(reps):
-                orc.energy_function(icrfs[b], dn_h, sd_h if with_std else None, 5, 250, t)
-            row["oracle_us_per_candidate"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
-            row["speedup_per_candidate"] = round(row["oracle_us_per_candidate"] / row["us_per_candidate"], 1)
         out["energy"].append(row)
         print("energy", row, flush=True)
 
