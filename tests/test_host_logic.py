@@ -196,3 +196,22 @@ def test_settings_configure():
         settings.configure(NOPE=1)
     with pytest.raises(NotImplementedError):
         settings.configure(BITS=1024)
+
+
+def test_oracle_is_test_infrastructure_only():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs may import the oracle: the product package,
+    the tools and the examples must not (a product path that routes through the oracle would void every parity claim)."""
+    import pathlib
+    import re
+    root = pathlib.Path(__file__).resolve().parent.parent
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    offenders = []
+    for sub in ("camera_linearity_amd", "tools", "examples"):
+        for f in (root / sub).rglob("*.py"):
+            if pat.search(f.read_text()):
+                offenders.append(str(f.relative_to(root)))
+    assert offenders == []
+    # bench.py and __graft_entry__.py import it only inside the baseline / smoke functions, never at module level
+    for name in ("bench.py", "__graft_entry__.py"):
+        src = (root / name).read_text()
+        assert not re.search(r"^(from\s+oracle\b|import\s+oracle\b)", src, re.M), name
