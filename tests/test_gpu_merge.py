@@ -627,3 +627,12 @@ def test_merge_full_size_properties(eng):
     got = out.reshape(-1, 3)
     assert bool((got == got[0]).all())
     np.testing.assert_allclose(host(got[0]), expect, rtol=1e-14)
+
+
+def test_config1_shape_identity_icrf(eng):
+    """BASELINE configs[0] on the GPU path: 3 x 256 x 256 x 3, identity ICRF, against the oracle."""
+    frames, _, t = orc.synthetic_stack(0, 3, 256, 256)
+    icrf = np.stack([np.arange(256) / 255.0] * 3, axis=1)
+    ref = orc.merge(frames, t, icrf)
+    out = eng.merge([dev(f) for f in frames], t, icrf)
+    close(host(out["val"]), ref["val"], VAL_RTOL)

@@ -195,3 +195,16 @@ def test_energy_function_matches_reference(golden):
                                g["abs_plain"], rtol=RTOL, equal_nan=True)
     np.testing.assert_allclose(orc.analyze_linearity_pairs(c[g["dn"]], g["sd"], c[lo], c[up], False, g["exposures"]),
                                g["abs_std"], rtol=RTOL, equal_nan=True)
+
+
+def test_config1_shape_identity_icrf():
+    """BASELINE configs[0]: 3-frame 256x256x3 uint8 stack, identity ICRF, CPU merge - the plumbing case. With the identity
+    ICRF the radiance is the weighted mean of DN/255/t: checked against a direct evaluation, and the index against the DNs."""
+    frames, _, t = orc.synthetic_stack(0, 3, 256, 256)
+    icrf = np.stack([np.arange(256) / 255.0] * 3, axis=1)
+    out = orc.merge(frames, t, icrf)
+    assert out["val"].shape == (256, 256, 3) and all(np.array_equal(i, f) for i, f in zip(out["idx"], frames))
+    w_lut = orc.gaussian_weight_lut()[0]
+    num = sum(w_lut[f] * (f / 255.0) / ti for f, ti in zip(frames, t))
+    den = sum(w_lut[f] for f in frames)
+    np.testing.assert_allclose(out["val"], num / den, rtol=1e-13)
