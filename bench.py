@@ -37,6 +37,7 @@ WORKLOADS = {
     "cfg3hot": (7, 4096, 4096, True, "hot"),    # std + dark hot-pixel maps
     "cfg4tile": (15, 1024, 8192, False, False),  # configs[3]: one of 8 row tiles of 15 x 8192 x 8192 x 3
     "cfg4tilestd": (15, 1024, 8192, True, False),  # configs[3] "+std" variant of the same tile
+    "cfg5": (7, 4096, 4096, False, False),      # configs[4]: 64 independent config-2 stacks on 8 GPUs = 8 resident stacks per GPU, one step merges all 8
     "cfg2rand": (7, 4096, 4096, False, False),  # config 2 with uniform-random DNs: the worst case for LDS bank conflicts
     "cfg2f64": (7, 4096, 4096, False, False),   # 64-bit mode (image_set.py:225): float64 frames, analytic weights, computed index
     "cfg3f64std": (7, 4096, 4096, True, False),  # 64-bit mode with std
@@ -215,6 +216,22 @@ def main():
             kw.update(darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, 0.05)] * n, median_k=3)
     plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds, variant=a.variant, **kw)
     alg_bytes = plan.algorithmic_bytes
+    stacks_per_step = 1
+    if a.workload == "cfg5":                 # 8 distinct resident stacks per GPU; a step = 8 launches (one per stack)
+        stacks_per_step = 8
+        plans = [plan]
+        for k in range(1, stacks_per_step):
+            fk, _, _ = synthetic_stack_device(100 * k + 7 + rank, n, H, W, device=dev, with_std=False)
+            plans.append(engine.plan_merge(fk, t, icrf, None, None, variant=a.variant))
+
+        class _Batch:                        # same interface as a MergePlan for the timing code below
+            outputs = plan.outputs
+
+            @staticmethod
+            def launch():
+                for p_ in plans:
+                    p_.launch()
+        plan = _Batch
 
     def barrier():
         torch.cuda.synchronize()
@@ -244,7 +261,7 @@ def main():
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps
+    avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps / stacks_per_step      # per hm_merge launch
     per = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 20))]
     for e0, e1 in per:
         e0.record()
@@ -286,7 +303,7 @@ def main():
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        mpix = world * a.steps * H * W / elapsed / 1e6
+        mpix = world * a.steps * stacks_per_step * H * W / elapsed / 1e6
         line = {
             "metric": "HDR-merged Mpix/s (node)", "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 5),
@@ -296,7 +313,7 @@ def main():
                                       ("float64 std propagation" if with_std else "val-only merge"))
                                    + " -> float64 radiance" + (" + uncertainty" if with_std else ""),
                        "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3,
-                       "parallelism": f"independent stacks x{world}, no collective", "variant": a.variant},
+                       "parallelism": f"independent stacks x{world * stacks_per_step} ({stacks_per_step} resident per GPU), no collective", "variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "merge_u8_fast", "algorithmic_bytes_per_launch": alg_bytes,
