@@ -85,6 +85,15 @@ class ImageSet(object):
     def use_cupy(self, new_value):
         raise AttributeError("use_cupy is a read-only attribute, managing the state of the used array backend.")
 
+    def to_cupy(self):
+        """image_set.py:95-100 moves the image to the CuPy backend; this package's device backend is HIP and an ImageSet
+        built here already lives there."""
+        raise NotImplementedError("camera_linearity_amd keeps images on the HIP backend (measurand.backend == 'hip'); there is no CuPy backend")
+
+    def show_image(self):
+        """image_set.py:423-433 opens an OpenCV window; no GUI in this package - use to_numpy() with the viewer of your choice."""
+        raise NotImplementedError("show_image needs an OpenCV GUI; use ImageSet.to_numpy() and display the array yourself")
+
     def to_numpy(self):
         """(val, std) host arrays of the managed image."""
         return self.measurand.to_numpy()
