@@ -300,6 +300,38 @@ class ImageSet(object):
         return out
 
 
+def _bias_subtract_directory(bias_dir: Path, source_dir: Path, save_dir: Path):
+    """Common body of calibrate_flats / calibrate_dark_frames (image_set.py:504-539): the shortest-exposure frame of `bias_dir`
+    is the bias; every image of `source_dir` has it subtracted (Measurand.__sub__, with uncertainty) and is saved as 8-bit
+    under `save_dir` with its own file name."""
+    darks = ImageSet.multiple_from_path(Path(bias_dir))
+    if not darks:
+        raise FileNotFoundError(f"no dark frames in {bias_dir}")
+    darks.sort(key=lambda image_set: image_set.features["exposure"])
+    bias = darks[0]
+    bias.load_value_image()
+    bias.load_std_image()
+    out = []
+    for image_set in ImageSet.multiple_from_path(Path(source_dir)):
+        image_set.load_value_image()
+        image_set.load_std_image()
+        image_set.measurand = image_set.measurand - bias.measurand
+        image_set.save_8bit(Path(save_dir) / image_set.path.name)
+        out.append(image_set)
+    return out
+
+
+def calibrate_flats(dark_path: Path, uncalibrated_flat_path: Path, flat_path: Path):
+    """image_set.py:504-521 with the three directories as arguments (the reference reads them from its config:
+    gs.DEFAULT_DARK_PATH, gs.UNCALIBRATED_FLAT_PATH, gs.DEFAULT_FLAT_PATH)."""
+    return _bias_subtract_directory(dark_path, uncalibrated_flat_path, flat_path)
+
+
+def calibrate_dark_frames(uncalibrated_dark_path: Path, dark_path: Path):
+    """image_set.py:524-539: bias-subtract the raw dark frames (the bias is the shortest of them) into `dark_path`."""
+    return _bias_subtract_directory(uncalibrated_dark_path, uncalibrated_dark_path, dark_path)
+
+
 def _features_from_file_name(file_path: Path):
     """image_set.py:542-568."""
     feature_dict = {"illumination": "", "magnification": "", "exposure": 0.0, "subject": ""}

@@ -293,3 +293,30 @@ def test_merge_pipeline_matches_oracle(eng, with_std, depth, count):
     assert seen == [0, 1, 2]
     with pytest.raises(ValueError):
         MergePipeline(n, h, w, t, icrf, diff, depth=1)
+
+
+def test_calibrate_flats_and_darks_from_disk(eng, tmp_path):
+    """calibrate_flats / calibrate_dark_frames (image_set.py:504-539): bias subtraction through Measurand.__sub__ and 8-bit
+    saving, directories as arguments."""
+    from camera_linearity_amd import tiff_io
+    from camera_linearity_amd.image_set import calibrate_dark_frames, calibrate_flats
+    rng = np.random.default_rng(3)
+    raw_dark, dark, raw_flat, flat = (tmp_path / d for d in ("raw_dark", "dark", "raw_flat", "flat"))
+    for d in (raw_dark, raw_flat):
+        d.mkdir()
+    bias = rng.integers(0, 8, (20, 30, 3), dtype=np.uint8)
+    darks = {"1ms": bias, "50ms": (bias + rng.integers(0, 20, (20, 30, 3))).astype(np.uint8)}
+    for name, img in darks.items():
+        tiff_io.imwrite(raw_dark / f"{name} dark.tif", img)
+    flat_img = rng.integers(150, 240, (20, 30, 3), dtype=np.uint8)
+    tiff_io.imwrite(raw_flat / "10ms flat.tif", flat_img)
+    out = calibrate_dark_frames(raw_dark, dark)
+    assert len(out) == 2
+    got = tiff_io.imread(dark / "50ms dark.tif")
+    want = np.around((darks["50ms"].astype(np.float64) / 255 - bias.astype(np.float64) / 255) * 255).astype(np.uint8)
+    assert np.array_equal(got, want)
+    assert not tiff_io.imread(dark / "1ms dark.tif").any()                       # bias minus itself
+    calibrate_flats(raw_dark, raw_flat, flat)
+    got = tiff_io.imread(flat / "10ms flat.tif")
+    want = np.around((flat_img.astype(np.float64) / 255 - bias.astype(np.float64) / 255) * 255).astype(np.uint8)
+    assert np.array_equal(got, want)
