@@ -373,50 +373,22 @@ class HipMeasurand(AbstractMeasurand):
         return {"mean": mean, "std": sd, "error": err}
 
     def compute_kernel_density_estimate(self, data_points: int, included_range=None, channels=None, use_std: bool = False):
-        """modules/measurand.py:716-761 (NumpyMeasurand only in the reference as well): scipy.stats.gaussian_kde per channel
-        with Silverman's bandwidth, optionally weighted by 1/std. Evaluated on the host like the reference - it feeds plots,
-        not the merge path - from one device-to-host copy of the arrays. -> {channel: (kde values, x range)}."""
-        from scipy.stats import gaussian_kde
-        if channels is None:
-            channels = list(range(gs.NUM_OF_CHS))
-        v, s = self.to_numpy()
-        estimates = {}
-        for c in channels:
-            cv = v[..., c]
-            mask = np.isfinite(cv)
-            weights = None
-            if use_std:
-                sc = s[..., c]
-                mask = np.logical_and(mask, sc != 0)
-                weights = 1 / sc[mask]
-            cv = cv[mask]
-            if included_range is None:
-                x_range = np.linspace(np.min(cv), np.max(cv), num=data_points)
-            else:
-                x_range = np.linspace(included_range[0], included_range[1], num=data_points)
-            estimates[c] = (gaussian_kde(cv, "silverman", weights=weights).evaluate(x_range), x_range)
-        return estimates
+        """modules/measurand.py:716-761 is a NumPy-only plotting helper of the reference (scipy.stats.gaussian_kde on host arrays)
+        and is out of scope here: this package computes on the device only."""
+        raise NotImplementedError("kernel density estimates are host-side plotting support in the reference; "
+                                  "use to_numpy() and scipy.stats.gaussian_kde")
 
     def compute_channel_histogram(self, bins: int, included_range=None, channels=None, use_std: bool = False):
         """modules/measurand.py:430-469: np.histogram per channel - hm_channel_histogram on the device (per-workgroup
-        LDS histograms), host NumPy only for more than 4 channels or more than 2048 bins."""
+        LDS histograms); up to 4 channels and bins * channels <= 8192."""
         if channels is None:
             channels = list(range(gs.NUM_OF_CHS))
         vd = self._f64()
-        if vd.is_cuda and vd.shape[-1] <= 4 and bins * vd.shape[-1] <= 8192:
-            return _engine().channel_histogram(vd, self.std if use_std else None, bins, included_range, channels)
-        v, s = self.to_numpy()
-        out = {}
-        for c in channels:
-            cv = v[..., c]
-            mask = np.isfinite(cv)
-            weights = None
-            if use_std:
-                sc = s[..., c]
-                mask = np.logical_and(mask, sc != 0)
-                weights = 1 / sc[mask]
-            out[c] = np.histogram(cv[mask], bins=bins, range=included_range, weights=weights)
-        return out
+        if not vd.is_cuda:
+            raise RuntimeError("compute_channel_histogram needs the image on the device (there is no CPU fallback)")
+        if vd.shape[-1] > 4 or bins * vd.shape[-1] > 8192:
+            raise NotImplementedError("hm_channel_histogram supports up to 4 channels and bins * channels <= 8192")
+        return _engine().channel_histogram(vd, self.std if use_std else None, bins, included_range, channels)
 
     @staticmethod
     def compute_difference(x: "HipMeasurand", y: "HipMeasurand", multiplier: float):
