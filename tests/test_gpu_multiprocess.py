@@ -1,0 +1,82 @@
+"""N > 1 path with the real HIP kernels: three processes (one per rank, gloo group, all on the one GPU of the test box - the
+scaling runs give each rank its own GPU) each merge their row tile with the median halo through hm_merge and the tiles are
+gathered host-side on rank 0 (camera_linearity_amd/parallel.py): bit-identical to the whole image merged by one process."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import hdr_oracle as orc  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs():
+    n, h, w = 5, 61, 40
+    frames, stds, t = orc.synthetic_stack(31, n, h, w, with_std=True)
+    rng = np.random.default_rng(31)
+    dark = (rng.random((h, w, 3)) < 0.02).astype(np.uint8) * 200
+    dark[0, 0, 0] = dark[h - 1, w - 1, 1] = 255
+    flat = rng.integers(160, 240, (h, w, 3)).astype(np.uint8)
+    flat_std = np.full((h, w, 3), 0.002)
+    icrf, diff = orc.synthetic_icrf()
+    return frames, stds, t, dark, flat, flat_std, icrf, diff
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from camera_linearity_amd import parallel
+        frames, stds, t, dark, flat, flat_std, icrf, diff = _inputs()
+        r0, r1, val, std = parallel.merge_row_tile(frames, t, icrf, diff, stds_host=stds, darks_host=[None, dark, dark, dark, dark],
+                                                   dark_min=[256, 13, 13, 13, 13], median_k=3, flat_host=flat, flat_std_host=flat_std,
+                                                   ff_mean=[0.78, 0.8, 0.79], ff_std_mean=[0.002] * 3, rank=rank, world_size=world)
+        assert (r0, r1) == parallel.row_tile_bounds(frames[0].shape[0], world)[rank]
+        gval, gstd = parallel.gather_row_tiles(val, std, dst=0)
+        if rank == 0:
+            q.put((gval, gstd))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:          # surface the failure to the parent instead of letting it wait for the queue
+        q.put(("error", f"rank {rank}: {type(e).__name__}: {e}"))
+        raise
+
+
+def test_row_tiles_three_ranks_on_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    from camera_linearity_amd import engine
+    frames, stds, t, dark, flat, flat_std, icrf, diff = _inputs()
+    dev = torch.device("cuda", 0)
+    dk = torch.as_tensor(dark, device=dev)
+    whole = engine.merge([torch.as_tensor(f, device=dev) for f in frames], t, icrf, diff, [torch.as_tensor(s, device=dev) for s in stds],
+                         darks=[None, dk, dk, dk, dk], dark_min=[256, 13, 13, 13, 13], median_k=3,
+                         flat=torch.as_tensor(flat, device=dev), flat_std=torch.as_tensor(flat_std, device=dev),
+                         ff_mean=[0.78, 0.8, 0.79], ff_std_mean=[0.002] * 3)
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=150)
+    assert got[0] is not None and not (isinstance(got[0], str) and got[0] == "error"), got
+    gval, gstd = got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(gval, whole["val"].cpu().numpy())
+    assert np.array_equal(gstd, whole["std"].cpu().numpy())
