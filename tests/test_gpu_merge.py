@@ -636,3 +636,28 @@ def test_config1_shape_identity_icrf(eng):
     ref = orc.merge(frames, t, icrf)
     out = eng.merge([dev(f) for f in frames], t, icrf)
     close(host(out["val"]), ref["val"], VAL_RTOL)
+
+
+def test_concurrent_streams(eng):
+    """hm_merge is re-entrant and stream-ordered: four stacks merged concurrently on four HIP streams (launches interleaved from
+    one host thread, hot-pixel fix-up passes included) give the results of serial launches."""
+    icrf, diff = orc.synthetic_icrf()
+    dark = dev((np.random.default_rng(2).random((96, 128, 3)) < 0.01).astype(np.uint8) * 220)
+    plans, serial = [], []
+    for k in range(4):
+        frames, stds, t = orc.synthetic_stack(70 + k, 6, 96, 128, with_std=True)
+        p = eng.plan_merge([dev(f) for f in frames], t, icrf, diff, [dev(s) for s in stds], darks=[dark] * 6, dark_min=[13] * 6, median_k=3)
+        p.launch()
+        torch.cuda.synchronize()
+        serial.append((p.outputs["val"].clone(), p.outputs["std"].clone()))
+        p.outputs["val"].zero_(); p.outputs["std"].zero_()
+        plans.append(p)
+    streams = [torch.cuda.Stream() for _ in plans]
+    torch.cuda.synchronize()
+    for rep in range(5):                                  # interleave launches across the streams
+        for p, s in zip(plans, streams):
+            p.launch(stream=s.cuda_stream)
+    for s in streams:
+        s.synchronize()
+    for p, (v, sd) in zip(plans, serial):
+        assert torch.equal(p.outputs["val"], v) and torch.equal(p.outputs["std"], sd)
