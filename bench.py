@@ -6,12 +6,16 @@
 
 A step = one fused merge launch over one synthetic exposure stack that is already resident in HBM.
 Workload (BASELINE.json configs[1], the one the metric is quoted on): 7 x 4096 x 4096 x 3 uint8 frames
-+ 256-entry ICRF, val-only merge -> float64 radiance. At N > 1 every rank merges its own stack of the
-same size (independent units, no data-path collective; "weak" scaling); value = all ranks' pixels /
-max-over-ranks time. The roofline block prices the dominant kernel (merge_u8_fast) from its average
-launch duration measured with HIP events on the launch stream inside the timed region; the cpu_baseline
-block times the NumPy oracle (a port of the reference's merge arithmetic) on a bounded row band of the
-same stack on the host, rank 0, N = 1 only.
++ 256-entry ICRF, val-only merge -> float64 radiance. FOUR distinct stacks are resident and merged round-robin, so
+no launch re-reads the inputs of the one before it (cold inputs; the figure for re-merging ONE stack is reported beside
+it as roofline.same_stack_*). At N > 1 every rank merges its own stacks of the same size (independent units, no
+data-path collective; "weak" scaling); value = all ranks' pixels / max-over-ranks time. The roofline block prices the
+kernel hm_merge dispatches to (its name comes from the library: hm_merge_describe) from its average launch duration
+measured with HIP events on the launch stream inside the timed region; the cpu_baseline block times the NumPy oracle
+(a port of the reference's merge arithmetic) on a bounded row band of the same stack on the host, rank 0, N = 1 only,
+and checks the GPU output of the timed configuration against it.
+Other workloads (--workload): cfg3* = configs[2] and its parts, cfg4 / cfg4std = configs[3] (ONE 15 x 8192 x 8192 x 3 image
+in 8 row tiles dealt to the ranks, host-side assembly), cfg5 = configs[4], cfg2rand, cfg2f64 / cfg3f64std, welford, energy.
 """
 import argparse
 import json
@@ -44,18 +48,6 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(frames, t, icrf, diff, stds, band_rows):
-    """NumPy oracle on rows [0, band_rows) of the bench stack, single thread (NumPy elementwise ops do not
-    multi-thread). kind = "port": the oracle restates the reference's arithmetic (oracle/hdr_oracle.py)."""
-    from oracle import hdr_oracle as orc
-    fh = [f[:band_rows].cpu().numpy() for f in frames]
-    sh = None if stds is None else [s[:band_rows].cpu().numpy() for s in stds]
-    t0 = time.perf_counter()
-    out = orc.merge(fh, t, icrf, diff, stds=sh)
-    dt = time.perf_counter() - t0
-    return out, dt
-
-
 def cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads):
     """The same oracle, row-tiled over a thread pool (NumPy releases the GIL inside its element-wise loops): the all-core
     number SURVEY.md 8(d) asks to show beside the single-thread one. Bands of 128 rows."""
@@ -72,6 +64,173 @@ def cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads):
     with ThreadPoolExecutor(max_workers=threads) as pool:
         list(pool.map(one, bands))
     return time.perf_counter() - t0
+
+
+DARK_THR = 0.05                 # pixel threshold of the dark maps (settings.DARK_THRESHOLD)
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the PMC pass of THIS round's profile run (tools/profile.sh -> profiles/r02_pmc_traffic.json,
+    which records the commit and workload it was collected on); None when there is no such record for the workload."""
+    tp = ROOT / "profiles" / "r02_pmc_traffic.json"
+    if not tp.exists():
+        return None, None
+    try:
+        rec = json.load(open(tp))
+    except Exception:
+        return None, None
+    ent = rec.get(workload)
+    if not ent:
+        return None, None
+    return ent.get("hbm_bytes_per_launch"), f"profiles/r02_pmc_traffic.json ({ent.get('kernel', '?')} @ {ent.get('commit', '?')})"
+
+
+def cpu_leg(a, plan, stack, icrf, diff, rows, n, H, W, with_std, corr):
+    """NumPy oracle (a port of the reference's merge arithmetic, oracle/hdr_oracle.py) on rows [0, rows) of the bench stack
+    - plus one halo row below when dark maps are on, so that the 3 x 3 medians of the last compared row see their true
+    neighbours - single thread, timed; its output is the parity check of the GPU result the timed launches produced."""
+    from oracle import hdr_oracle as orc
+    hot = corr in (True, "hot")
+    flat_on = corr in (True, "flat")
+    band = min(rows + (1 if hot else 0), H)
+    host = lambda x: x[:band].cpu().numpy()                                              # noqa: E731
+    fh = [host(f) for f in stack["frames"]]
+    sh = None if stack["stds"] is None else [host(s_) for s_ in stack["stds"]]
+    kw = {}
+    if hot:
+        dv = orc.unit_from_u8(host(stack["dark"]))
+        kw.update(darks=[dv] * n, dark_threshold=DARK_THR, median_k=3)
+    if flat_on:
+        fk = stack["kw"]
+        kw.update(flat=orc.unit_from_u8(host(stack["flat"])), flat_std=host(stack["flat_std"]), ff_mean=np.asarray(fk["ff_mean"]),
+                  ff_std_mean=np.asarray(fk["ff_std_mean"]))
+    t0 = time.perf_counter()
+    ref = orc.merge(fh, stack["t"], icrf, diff if with_std else None, stds=sh, **kw)
+    dt = time.perf_counter() - t0
+    plan.launch()
+    torch.cuda.synchronize()
+
+    def max_rel(got, want):
+        got, want = got[:rows], want[:rows]
+        err = np.abs(got - want)
+        den = np.abs(want)
+        nz = den > 0                                     # radiance is exactly 0 where every frame has DN 0 (ICRF[0] = 0)
+        return float(max(np.max(err[nz] / den[nz]) if nz.any() else 0.0, np.max(err[~nz]) if (~nz).any() else 0.0))
+    rv = max_rel(plan.outputs["val"][:band].cpu().numpy(), ref["val_ff"] if flat_on else ref["val"])
+    rs = None
+    if with_std:
+        rs = max_rel(plan.outputs["std"][:band].cpu().numpy(), ref["std_ff"] if flat_on else ref["std"])
+    tol_v = 1e-11 if "f64" in a.workload else 1e-12
+    cpu = {"value": round(band * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": f"rows 0..{band - 1} of the bench stack ({n}x{band}x{W}x3, {dt:.1f} s), NumPy oracle, 1 thread of "
+                     f"{os.cpu_count()} host cores" + ("; rows 0.." + str(rows - 1) + " compared" if band != rows else ""),
+           "gpu_vs_oracle_max_rel_err": rv, "gpu_vs_oracle_max_rel_err_std": rs,
+           "parity_ok": bool(rv <= tol_v and (rs is None or rs <= 1e-9))}
+    threads = min(16, os.cpu_count() or 1)          # the one-GPU box's CPU share
+    if threads > 1 and not corr:
+        dt_t = cpu_baseline_threaded(stack["frames"], stack["t"], icrf, diff if with_std else None, stack["stds"], rows, threads)
+        cpu["threaded"] = {"value": round(rows * W / dt_t / 1e6, 4), "unit": "Mpix/s", "cores": threads,
+                           "sample": f"same rows, 128-row bands on a {threads}-thread pool ({dt_t:.1f} s)"}
+    return cpu
+
+
+def row_tile_workload(a, dev, rank, world, dist):
+    """BASELINE.json configs[3] as written: ONE 15-frame 8192 x 8192 x 3 stack cut into 8 row tiles of 1024 rows; the 8 tiles
+    are dealt to the ranks (rank r merges tiles r, r + N, ...; N = 1 merges all 8 back to back), each tile is one fused
+    launch on that rank's GPU, no data-path collective. A step = every rank merges all its tiles once; value = whole-image
+    Mpix per second (total work is fixed: "strong" scaling). After the timed region the image is assembled ONCE on rank 0
+    (pinned buffers, asynchronous D2H on a side stream, tensor send / receive over a gloo group) - reported as
+    `assembly_ms`, never part of `value`."""
+    from camera_linearity_amd import parallel
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf
+    n, H, W, n_tiles = 15, 8192, 8192, 8
+    with_std = a.workload == "cfg4std"
+    icrf, diff = synthetic_icrf()
+    tiles = parallel.RowTileSet(H, n_tiles, rank, world)
+    keep = {}
+    for tile in tiles.mine:                             # tile t of the image is generated from seed 7 + t whichever rank owns it
+        r0, r1 = tiles.bounds[tile]
+        frames, stds, t = synthetic_stack_device(7 + tile, n, r1 - r0, W, device=dev, with_std=with_std)
+        tiles.add_tile(tile, frames, t, icrf, diff if with_std else None, stds, variant=a.variant)
+        keep[tile] = (frames, stds, t)
+    alg = tiles.algorithmic_bytes                       # this rank's bytes per step
+    n_launch = len(tiles.mine)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    t_end = time.perf_counter() + a.prewarm_s
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            tiles.launch()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        tiles.launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        tiles.launch()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps / max(n_launch, 1)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    # host-side assembly of the image (once, untimed for `value`)
+    gloo = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
+    barrier()
+    ta = time.perf_counter()
+    val, std = tiles.assemble(group=gloo, dst=0)
+    assembly_ms = (time.perf_counter() - ta) * 1e3
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import hdr_oracle as orc
+        rows = a.cpu_rows if a.cpu_rows > 0 else (192 if with_std else 384)
+        tile = n_tiles // 2 if n_tiles // 2 in tiles.mine else tiles.mine[0]           # an interior tile (row0 = 4096)
+        frames, stds, t = keep[tile]
+        fh = [f[:rows].cpu().numpy() for f in frames]
+        sh = None if stds is None else [s_[:rows].cpu().numpy() for s_ in stds]
+        c0 = time.perf_counter()
+        ref = orc.merge(fh, t, icrf, diff if with_std else None, stds=sh)
+        dt = time.perf_counter() - c0
+        r0 = tiles.bounds[tile][0]
+        got = val[r0:r0 + rows].numpy()                                                 # out of the ASSEMBLED image
+        den = np.abs(ref["val"])
+        nz = den > 0
+        rv = float(np.max(np.abs(got - ref["val"])[nz] / den[nz]))
+        rs = None
+        if with_std:
+            rs = float(np.max(np.abs(std[r0:r0 + rows].numpy() - ref["std"]) / np.abs(ref["std"])))
+        cpu = {"value": round(rows * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+               "sample": f"rows {r0}..{r0 + rows - 1} of the image = the first {rows} rows of tile {tile} ({n}x{rows}x{W}x3, {dt:.1f} s), "
+                         f"NumPy oracle, 1 thread of {os.cpu_count()} host cores; compared with the same rows of the assembled image",
+               "gpu_vs_oracle_max_rel_err": rv, "gpu_vs_oracle_max_rel_err_std": rs, "parity_ok": bool(rv <= 1e-12 and (rs is None or rs <= 1e-9))}
+    if rank == 0:
+        plan0 = tiles.plans[tiles.mine[0]]
+        achieved = alg / n_launch / avg_us / 1e3
+        line = {"metric": "HDR-merged Mpix/s (node)", "value": round(a.steps * H * W / elapsed / 1e6, 1), "unit": "Mpix/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 5), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"ONE {n}x{H}x{W}x3 uint8 exposure stack in {n_tiles} row tiles of {H // n_tiles} rows dealt to {world} GPU(s), "
+                                       + ("float64 std propagation" if with_std else "val-only merge") + ", host-side assembly (untimed)",
+                           "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3, "row_tiles": n_tiles,
+                           "parallelism": f"row tiles: {n_launch} per GPU, no collective on the data path", "variant": a.variant},
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None, "kernel": plan0.kernels,
+                             "algorithmic_bytes_per_launch": alg // n_launch, "avg_launch_us": round(avg_us, 2)},
+                "assembly_ms": round(assembly_ms, 1),
+                "assembly": f"{n_tiles} tiles -> pinned host buffers (async D2H on a side stream) -> one {H}x{W}x3 float64 image"
+                            + (" (+ std)" if with_std else "") + " on rank 0",
+                "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def producer_workload(a, dev):
@@ -155,14 +314,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["welford", "energy"])
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4", "cfg4std", "welford", "energy"])
+    ap.add_argument("--stacks", type=int, default=0, help="distinct resident stacks merged round-robin (0 = 4 for cfg2 / cfg2rand, 1 otherwise)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even at world size 1")
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
-    ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the stack the CPU baseline merges")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the stack the CPU baseline merges (0 = per workload: 4096 val-only, 512 with std / corrections)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,41 +357,60 @@ def main():
     from camera_linearity_amd import engine
     from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
 
+    if a.workload in ("cfg4", "cfg4std"):             # configs[3] as specified: ONE 15 x 8192 x 8192 x 3 image in 8 row tiles
+        row_tile_workload(a, dev, rank, world, dist)
+        return
     n, H, W, with_std, corr = WORKLOADS[a.workload]
-    frames, stds, t = synthetic_stack_device(7 + rank, n, H, W, device=dev, with_std=with_std)
-    if "f64" in a.workload:
-        frames = [engine.u8_to_unit(f) for f in frames]
-    if a.workload == "cfg2rand":
-        gen = torch.Generator(device=dev).manual_seed(7 + rank)
-        frames = [torch.randint(0, 256, f.shape, dtype=torch.uint8, device=dev, generator=gen) for f in frames]
     icrf, diff = synthetic_icrf()
-    kw = {}
-    if corr:
-        flat, flat_std, dark = synthetic_flat_dark(7 + rank, H, W, device=dev)
-        x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
-        if corr in (True, "flat"):
-            kw.update(flat=flat, flat_std=flat_std, ff_mean=engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy(),
-                      ff_std_mean=engine.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy())
-        if corr in (True, "hot"):
-            kw.update(darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, 0.05)] * n, median_k=3)
-    plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds, variant=a.variant, **kw)
+    rotate = a.stacks if a.stacks > 0 else (4 if a.workload in ("cfg2", "cfg2rand") else 1)
+    if a.workload == "cfg5":
+        rotate = 1
+
+    def build_stack(seed):
+        frames, stds, t = synthetic_stack_device(seed, n, H, W, device=dev, with_std=with_std)
+        if "f64" in a.workload:
+            frames = [engine.u8_to_unit(f) for f in frames]
+        if a.workload == "cfg2rand":
+            gen = torch.Generator(device=dev).manual_seed(seed)
+            frames = [torch.randint(0, 256, f.shape, dtype=torch.uint8, device=dev, generator=gen) for f in frames]
+        kw = {}
+        extra = {}
+        if corr:
+            flat, flat_std, dark = synthetic_flat_dark(seed, H, W, device=dev)
+            extra.update(flat=flat, flat_std=flat_std, dark=dark)
+            x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
+            if corr in (True, "flat"):
+                kw.update(flat=flat, flat_std=flat_std, ff_mean=engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy(),
+                          ff_std_mean=engine.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy())
+            if corr in (True, "hot"):
+                kw.update(darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, DARK_THR)] * n, median_k=3)
+        plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds, variant=a.variant, **kw)
+        return plan, dict(frames=frames, stds=stds, t=t, kw=kw, **extra)
+
+    # R distinct resident stacks, merged round-robin: consecutive launches never re-read the previous launch's inputs, so no
+    # input byte can come out of the 256 MB Infinity Cache (one config-2 stack is 352 MB in + 403 MB out)
+    plans, stacks = [], []
+    for k in range(rotate):
+        p_, s_ = build_stack(7 + rank + 100 * k)
+        plans.append(p_)
+        stacks.append(s_)
+    plan, stack0 = plans[0], stacks[0]
     alg_bytes = plan.algorithmic_bytes
-    stacks_per_step = 1
+    launches_per_step = 1
     if a.workload == "cfg5":                 # 8 distinct resident stacks per GPU; a step = 8 launches (one per stack)
-        stacks_per_step = 8
-        plans = [plan]
-        for k in range(1, stacks_per_step):
-            fk, _, _ = synthetic_stack_device(100 * k + 7 + rank, n, H, W, device=dev, with_std=False)
-            plans.append(engine.plan_merge(fk, t, icrf, None, None, variant=a.variant))
+        launches_per_step = 8
+        for k in range(1, launches_per_step):
+            plans.append(build_stack(100 * k + 7 + rank)[0])
 
-        class _Batch:                        # same interface as a MergePlan for the timing code below
-            outputs = plan.outputs
+    counter = [0]
 
-            @staticmethod
-            def launch():
-                for p_ in plans:
-                    p_.launch()
-        plan = _Batch
+    def step():
+        if launches_per_step > 1:
+            for p_ in plans:
+                p_.launch()
+        else:
+            plans[counter[0] % len(plans)].launch()
+            counter[0] += 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -244,10 +423,10 @@ def main():
     t_end = time.perf_counter() + a.prewarm_s
     while time.perf_counter() < t_end:
         for _ in range(50):
-            plan.launch()
+            step()
         torch.cuda.synchronize()
     for _ in range(a.warmup):
-        plan.launch()
+        step()
     # HIP events on the launch stream (torch's current stream is the one hm_merge is given), bracketing the
     # K back-to-back launches of the timed region: average launch duration = event span / K. (An event pair
     # around EVERY launch would put a barrier packet between consecutive kernels and measure a different,
@@ -257,11 +436,23 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(a.steps):
-        plan.launch()
+        step()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps / stacks_per_step      # per hm_merge launch
+    avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps / launches_per_step      # per hm_merge call
+    # secondary figure: the same number of launches re-merging ONE stack (what round 1 reported as the headline)
+    same_us = None
+    if len(plans) > 1 and launches_per_step == 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            plan.launch()
+        e0.record()
+        for _ in range(a.steps):
+            plan.launch()
+        e1.record()
+        torch.cuda.synchronize()
+        same_us = e0.elapsed_time(e1) * 1e3 / a.steps
     per = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 20))]
     for e0, e1 in per:
         e0.record()
@@ -274,50 +465,38 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # parity spot check of the timed configuration against the oracle on a row band (not timed)
+    # CPU leg + parity check of the timed configuration against the oracle on a row band (not timed on the GPU side)
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not corr:
-        rows = min(a.cpu_rows, H)
-        ref, dt = cpu_baseline(frames, t, icrf, diff, stds, rows)
-        got = plan.outputs["val"][:rows].cpu().numpy()
-        err = np.abs(got - ref["val"])
-        denom = np.abs(ref["val"])
-        nz = denom > 0                                   # radiance is exactly 0 where every frame has DN 0 (ICRF[0] = 0)
-        max_rel = float(max(np.max(err[nz] / denom[nz]) if nz.any() else 0.0, np.max(err[~nz]) if (~nz).any() else 0.0))
-        cpu = {"value": round(rows * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
-               "sample": f"rows 0..{rows - 1} of the bench stack ({n}x{rows}x{W}x3, {dt:.1f} s), NumPy oracle, 1 thread of "
-                         f"{os.cpu_count()} host cores",
-               "gpu_vs_oracle_max_rel_err": max_rel, "parity_ok": bool(max_rel <= 1e-12)}
-        threads = min(16, os.cpu_count() or 1)          # the one-GPU box's CPU share
-        if threads > 1:
-            dt_t = cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads)
-            cpu["threaded"] = {"value": round(rows * W / dt_t / 1e6, 4), "unit": "Mpix/s", "cores": threads,
-                               "sample": f"same rows, 128-row bands on a {threads}-thread pool ({dt_t:.1f} s)"}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        frames, stds, t = stack0["frames"], stack0["stds"], stack0["t"]
+        rows = min(a.cpu_rows if a.cpu_rows > 0 else (4096 if not with_std and not corr else 512), H)
+        if "f64" in a.workload:
+            rows = min(rows, 1024)
+        cpu = cpu_leg(a, plan, stack0, icrf, diff, rows, n, H, W, with_std, corr)
 
     if rank == 0:
         achieved = alg_bytes / avg_us / 1e3          # GB/s
-        traffic = None
-        tp = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if tp.exists() and a.workload == "cfg2":
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        mpix = world * a.steps * stacks_per_step * H * W / elapsed / 1e6
+        traffic, traffic_src = measured_traffic(a.workload)
+        mpix = world * a.steps * launches_per_step * H * W / elapsed / 1e6
         line = {
             "metric": "HDR-merged Mpix/s (node)", "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n}x{H}x{W}x3 uint8 exposure stack per GPU, 256-entry ICRF LUT, "
-                                   + ("float64 std + dark hot-pixel maps + flat field" if corr else
-                                      ("float64 std propagation" if with_std else "val-only merge"))
-                                   + " -> float64 radiance" + (" + uncertainty" if with_std else ""),
-                       "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3,
-                       "parallelism": f"independent stacks x{world * stacks_per_step} ({stacks_per_step} resident per GPU), no collective", "variant": a.variant},
+                                   + ("float64 std + dark hot-pixel maps + flat field" if corr is True else
+                                      ("float64 std + " + ("flat field" if corr == "flat" else "dark hot-pixel maps") if corr else
+                                       ("float64 std propagation" if with_std else "val-only merge")))
+                                   + " -> float64 radiance" + (" + uncertainty" if with_std else "")
+                                   + (f"; {len(plans)} distinct resident stacks merged round-robin (cold inputs)" if len(plans) > 1 and launches_per_step == 1 else ""),
+                       "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3, "resident_stacks": len(plans),
+                       "parallelism": f"independent stacks x{world * max(launches_per_step, 1)} per step, no collective", "variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "merge_u8_fast", "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": round(avg_us, 2), "isolated_launch_us_min_median": [round(float(np.min(kernel_us)), 2), round(float(np.median(kernel_us)), 2)]},
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": plan.kernels, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": round(avg_us, 2),
+                         "same_stack_avg_launch_us": None if same_us is None else round(same_us, 2),
+                         "same_stack_frac": None if same_us is None else round(alg_bytes / same_us / 1e3 / HBM_PEAK_GBPS, 4),
+                         "isolated_launch_us_min_median": [round(float(np.min(kernel_us)), 2), round(float(np.median(kernel_us)), 2)]},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "hm_linearize_f64": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "hm_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
     "hm_merge_algorithmic_bytes": (C.c_int64, [C.POINTER(MergeArgs)]),
+    "hm_merge_describe": (C.c_int, [C.POINTER(MergeArgs), C.c_char_p, C.c_int]),
     "hm_hot_pixel_filter_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                          C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "hm_hot_pixel_filter_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
@@ -72,6 +73,9 @@ _SIGNATURES = {
     "hm_binary_op": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                               C.POINTER(C.c_int64), C.c_void_p]),
     "hm_unary_op": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_pow_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "hm_take_axis": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                               C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     "hm_apply_thresholds": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p]),
     "hm_compute_difference": (C.c_int, [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p]),
     "hm_interpolate": (C.c_int, [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -98,16 +102,36 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+class _Lib:
+    """The loaded library with a per-symbol call counter (`lib.calls["hm_merge"]`): tests use it to assert that an
+    operation ran through the HIP kernel it is documented to use, not through some other path."""
+
+    def __init__(self, cdll):
+        import collections
+        self._cdll = cdll
+        self.calls = collections.Counter()
+
+    def _bind(self, name, res, args):
+        fn = getattr(self._cdll, name)          # AttributeError if the library lacks a declared entry point
+        fn.restype = res
+        fn.argtypes = args
+        calls = self.calls
+
+        def call(*a):
+            calls[name] += 1
+            return fn(*a)
+        call.__name__ = name
+        setattr(self, name, call)
+
+
 def _load():
     if not LIB_PATH.exists():
         raise ImportError(
             f"libhdrmerge.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C camera_linearity_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = _Lib(C.CDLL(str(LIB_PATH)))
     for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the library lacks a declared entry point
-        fn.restype = res
-        fn.argtypes = args
+        lib._bind(name, res, args)
     return lib
 
 

@@ -24,6 +24,9 @@
 //                     config 3 (3.6 ms -> under 1 ms); the scan reads each dark byte once, which is the
 //                     d*N term of the algorithmic byte count.
 #include "hm_common.h"
+#include <cstdio>
+#include <string>
+#include <type_traits>
 
 namespace hm {
 
@@ -56,6 +59,8 @@ struct MergeK {
     int64_t in_off;                        // (row0 - buf_row0) * W * C: offset of row0 inside the input buffers
     int64_t H, W, row0, buf_row0, buf_rows;
     int32_t n_frames, C, median_k, has_flat;
+    int32_t inv_t_inrange;                 // every 1/exposure in [2^-300, 2^300] (host check; see div_inrange)
+    int32_t variant;
 };
 
 __device__ __forceinline__ void elem_to_pixel(const MergeK& a, int64_t e, int64_t& row, int64_t& col, int& c) {
@@ -408,6 +413,29 @@ constexpr int kStdTabBytes = 16 * 256 + 16 * 768;
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p));
 }
+// the same load through an explicit global-address-space pointer: after an `asm volatile("+s")` pin the compiler no longer
+// knows that a kernarg pointer is global and would fall back to flat_load (which also counts against lgkmcnt)
+// 16-byte nontemporal load at (scalar base) + (32-bit byte offset in a VGPR) through an explicit global-address-space pointer:
+// after an `asm volatile("+s")` pin hipcc no longer knows that a kernarg pointer is global and emits flat_load, which
+// counts against lgkmcnt as well as vmcnt and so serialises with the LDS gathers around it.
+typedef const __attribute__((address_space(1))) f64x2* global_f64x2_ptr;
+typedef const __attribute__((address_space(1))) char* global_char_ptr;
+__device__ __forceinline__ f64x2 ld_f64x2_global(const double* scalar_base, uint32_t byte_off) {
+    global_char_ptr g = (global_char_ptr)(scalar_base);
+    return __builtin_nontemporal_load((global_f64x2_ptr)(g + byte_off));
+}
+
+// Buffer addressing for the frame bytes: the frame pointer sits in a 4-SGPR resource descriptor, the group's byte offset
+// in one SGPR shared by all frames (soffset), the lane's offset in one VGPR and the sub-unit in the immediate - a load
+// costs no address arithmetic at all (global_load needs a 64-bit VGPR address or a 64-bit scalar base per frame and group).
+// Raw buffer, stride 0, num_records = 2^32 - 1 bytes: offsets are below 2^32 because the fast kernels require E < 2^32.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
+}
+constexpr int kAuxNT = 2;                                             // cache-policy bits of the raw-buffer builtins on gfx94x/gfx950: nt
+__device__ __forceinline__ uint16_t ld_u16_buf(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t group_off) {
+    return __builtin_amdgcn_raw_buffer_load_b16(r, static_cast<int>(lane_off), static_cast<int>(group_off), kAuxNT);
+}
 // store two float64 at (scalar base) + (32-bit byte offset in a VGPR)
 __device__ __forceinline__ void store2(double* base, uint32_t byte_off, double x, double y) {
     f64x2 v; v.x = x; v.y = y;
@@ -641,7 +669,7 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
                     const double it = a.inv_t[i];
                     const double* sp = a.sd[i] + a.in_off + sbase;                               // scalar base
                     if (NF > HM_PIN_NF || !FLAT) asm volatile("" : "+s"(sp));     // keep base + 32-bit lane offset addressing (no per-frame VGPR address pairs)
-                    const f64x2 sdv = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(sp) + lane16));
+                    const f64x2 sdv = ld_f64x2_global(sp, lane16);
                     uint32_t packed = cur[i][s];
                     if (NF > HM_PIN_NF || !FLAT) HM_PIN(packed);                  // re-extract the DNs here instead of keeping pass 1's indices alive
 #pragma unroll
@@ -698,6 +726,194 @@ __global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const Merge
 template <int NF, int U, int TAB, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HM_STD_WAVES, HM_STD_WAVES))) void merge_u8_fast_std(const MergeK a) {
     merge_u8_fast_body<NF, U, TAB, true, PREFETCH, FLAT, SUMW, BLOCK>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge_u8_val3: val-only merge of uint8 frames, C == 3, compile-time N, no extras - the bench kernel (config 2).
+//
+// Element -> lane ownership is that of merge_u8_fast (lane l owns elements 2l, 2l+1 of a 128-element sub-unit: one
+// global_load_ushort per frame, one fully contiguous 1 KB global_store_dwordx4 per wave), what changes is everything
+// around the gathers, which rocprof showed to be the larger part of the VALU stream (profiles/r01g: 7.9 VALU
+// instructions per element-frame, 2 of them the float64 accumulation):
+//   * a wave's group is THREE sub-units = 384 elements = 128 whole pixels, so every group starts on channel 0 and the
+//     channel of element j of sub-unit s is (2s + 2l + j) % 3 - a compile-time function of (s, j) on top of the lane
+//     constant (2l) % 3. The three possible table offsets live in three VGPRs for the whole kernel; merge_u8_fast
+//     recomputed its channel offsets per sub-unit with 32-bit multiplies-high (% 3 of a run-time group index).
+//     The LDS address of a gather is then one v_mad_u32_u24 (dn * 48 + offset) after the byte extraction.
+//   * the next group's loads go into a second register set and the loop body is written out twice (A/B), so the
+//     prefetch costs no register-to-register copies (14 v_mov per 256 elements before).
+//   * acc / S uses the correctly rounded reciprocal-Newton-Markstein sequence WITHOUT the operand scaling and fix-up
+//     steps of the IEEE division expansion (v_div_scale x2, v_div_fixup: 3 of its 11 instructions) whenever the
+//     workgroup has proven, while building its tables, that no operand can leave the range in which those steps are
+//     the identity (div_inrange below); otherwise the plain division. Both give the same bits.
+// ------------------------------------------------------------------------------------------------
+
+// a / b, correctly rounded, for operands in the range the table check guarantees: b in [2^-64, 2^70] and a either +0 or
+// |a| in [2^-660, 2^610]. This is instruction for instruction what hipcc emits for a float64 division minus the two
+// v_div_scale_f64 (which return their operands unchanged in that range: no operand is denormal, the quotient and 1/b
+// are normal, the numerator's biased exponent is above 53 and the exponent difference below 768) and the
+// v_div_fixup_f64 (which only rewrites zero / infinite / NaN cases): r = rcp(b) refined twice, q = a r,
+// q' = q + (a - b q) r (Markstein). a = +0 gives +0 on both paths; -0 never reaches it (the check rejects tables that hold one).
+__device__ __forceinline__ double div_inrange(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    const double q = a * r;
+    const double res = fma(-b, q, a);
+    return fma(res, r, q);
+}
+template <bool FASTDIV>
+__device__ __forceinline__ double merge_div(double a, double b) {
+    if constexpr (FASTDIV) return div_inrange(a, b);
+    else return a / b;
+}
+// table entry check behind div_inrange: w in [2^-64, 2^64]; w*g either +0 (bit pattern) or |w*g| in [2^-300, 2^300]
+__device__ __forceinline__ bool entry_inrange(double w, double wg) {
+    const bool w_ok = w >= 0x1p-64 && w <= 0x1p64;
+    const double m = fabs(wg);
+    const bool wg_ok = __double_as_longlong(wg) == 0 || (m >= 0x1p-300 && m <= 0x1p300);
+    return w_ok && wg_ok;
+}
+
+// Template parameters (the defaults are chosen by launch_val3(); the others exist for A/B runs, tools/ab_val3.py):
+//   U    sub-units of 128 elements per wave and iteration (2 or 3).
+//   PF   0: in-place refill - each R register is reloaded with the next unit's bytes as soon as its DNs have been turned
+//           into LDS addresses (one register set, loads issued in bundles of HM_FB frames between the gathers);
+//        1: the next unit's loads are all issued at the top of the iteration into a second register set (A/B ping-pong).
+//   MAP  0: a wave owns U*128 contiguous elements per iteration ("group");
+//        1: the WORKGROUP owns U*512 contiguous elements ("chunk") and slot s of wave w sits at 512 s + 128 w, so the four
+//           waves' loads of one time slot cover 512 contiguous bytes of every frame and their stores 4 contiguous KB.
+// A unit (group or chunk) must start on channel 0 for the channel pattern to be a compile-time function of (s, j): its
+// size is a multiple of 3 when U == 3; for U == 2 the unit index advances by a multiple of 3 per iteration (the host
+// launches a multiple of 3 workgroups), so the phase is a per-wave constant folded into the lane's table offsets.
+template <int NF, int U, int PF, int MAP>
+__global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
+    __shared__ __attribute__((aligned(16))) char lds[16 * 768];
+    __shared__ uint32_t s_bad[4];
+    constexpr uint32_t SLOT = MAP ? 4u * kSub : kSub;              // element distance between a wave's consecutive slots
+    constexpr uint32_t UNIT = U * SLOT;                            // elements per unit (group: U*128, chunk: U*512)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave_el = MAP ? wave * kSub : 0u;               // scalar: the wave's element offset inside a chunk
+    const uint32_t lane2 = lane * 2u + wave_el;                    // element (= byte) offset of the lane's first element inside the unit
+    const uint32_t n_units = static_cast<uint32_t>(a.n_elems / UNIT);
+    const uint32_t ustride = MAP ? gridDim.x : gridDim.x * 4u;
+    uint32_t u = MAP ? blockIdx.x : blockIdx.x * 4u + wave;        // wave-uniform
+
+    // R[i][s]: the two DNs of frame i, slot s (kept 16-bit: widening at the load would put a v_and - and a wait for the
+    // load - right behind it)
+    // (PF == 1 keeps 32-bit registers filled by zero-extending global loads: with two 16-bit register sets hipcc packs pairs
+    // of them into one VGPR with v_perm_b32 at the loop back-edge, i.e. waits for the prefetch it has just issued)
+    using reg_t = std::conditional_t<PF == 0, uint16_t, uint32_t>;
+    reg_t RA[NF][U], RB[PF ? NF : 1][PF ? U : 1];
+    auto load_unit = [&](uint32_t unit, auto& dst) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if constexpr (PF == 0) {
+                const __amdgpu_buffer_rsrc_t fr = frame_rsrc(static_cast<const uint8_t*>(a.frame[i]) + a.in_off);
+#pragma unroll
+                for (int s = 0; s < U; ++s) dst[i][s] = ld_u16_buf(fr, lane2 + SLOT * s, unit * UNIT);
+            } else {
+                const uint8_t* p = static_cast<const uint8_t*>(a.frame[i]) + a.in_off + static_cast<int64_t>(unit) * UNIT;
+#pragma unroll
+                for (int s = 0; s < U; ++s) dst[i][s] = ld_u16(p + SLOT * s + lane2);
+            }
+        }
+    };
+    if (u < n_units) load_unit(u, RA);                                              // in flight while the tables are built
+
+    bool bad = false;
+    for (int q = threadIdx.x; q < 768; q += 256) {
+        const double w = a.w_lut[q / 3];
+        const double wg = w * a.icrf[q];                                            // (w * g), exposure_series.py:388
+        reinterpret_cast<double2*>(lds)[q] = double2{w, wg};
+        bad = bad || !entry_inrange(w, wg);
+    }
+    const bool wave_bad = __ballot(bad) != 0ull;
+    if (lane == 0) s_bad[wave] = wave_bad ? 1u : 0u;
+    __syncthreads();
+    const uint32_t any_bad = __builtin_amdgcn_readfirstlane(s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]);
+    const bool fastdiv = any_bad == 0u && a.inv_t_inrange != 0;                     // scalar
+    if (u >= n_units) return;
+
+    // channel of the lane's first element in slot 0: (unit start + wave offset + 2 lane) % 3; the unit start is a
+    // per-wave constant mod 3 (see above)
+    const uint32_t p0 = static_cast<uint32_t>((static_cast<uint64_t>(u) * UNIT) % 3u);
+    const uint32_t k = (p0 + lane2) % 3u;
+    const uint32_t off[3] = {k * 16u, ((k + 1u) % 3u) * 16u, ((k + 2u) % 3u) * 16u};
+
+    // one unit out of `cur`; REFILL (PF == 0 only): fetch the next unit's bytes into the registers this one frees
+    auto process = [&](auto refill_tag, uint32_t unit, auto& cur) {
+        constexpr bool REFILL = decltype(refill_tag)::value;
+        const uint32_t next_off = (unit + ustride) * UNIT;                                   // scalar: byte offset of the next unit in every frame
+        double* og = a.out_val + static_cast<int64_t>(unit) * UNIT + wave_el;                // scalar base of the wave's output in this unit
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            double S[2], acc[2];
+#pragma unroll
+            for (int i0 = 0; i0 < NF; i0 += HM_FB) {                                // HM_FB frames per scheduling bundle
+                uint32_t addr[HM_FB][2];
+#pragma unroll
+                for (int f = 0; f < HM_FB; ++f) {
+                    if (i0 + f < NF) {
+                        const reg_t r = cur[i0 + f][s];
+                        addr[f][0] = __umul24(static_cast<uint32_t>(r & 255u), 48u) + off[(2 * s) % 3];
+                        addr[f][1] = __umul24(static_cast<uint32_t>(r >> 8), 48u) + off[(2 * s + 1) % 3];
+                    }
+                }
+                if constexpr (REFILL) {
+                    __builtin_amdgcn_sched_barrier(0);      // the refill must not be hoisted above the last use of the old bytes (it would need a second register set)
+#pragma unroll
+                    for (int f = 0; f < HM_FB; ++f)
+                        if (i0 + f < NF)
+                            cur[i0 + f][s] = ld_u16_buf(frame_rsrc(static_cast<const uint8_t*>(a.frame[i0 + f]) + a.in_off), lane2 + SLOT * s, next_off);
+                }
+#pragma unroll
+                for (int f = 0; f < HM_FB; ++f) {
+                    if (i0 + f < NF) {
+                        const double it = a.inv_t[i0 + f];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const double2 t = *reinterpret_cast<const double2*>(lds + addr[f][j]);
+                            if (i0 + f == 0) { S[j] = t.x; acc[j] = t.y * it; }
+                            else {
+                                S[j] += t.x;                               // exposure_series.py:340
+                                acc[j] = fma(t.y, it, acc[j]);             // :388 numerator
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { HM_PIN(S[j]); HM_PIN(acc[j]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            double v0, v1;
+            if (fastdiv) { v0 = div_inrange(acc[0], S[0]); v1 = div_inrange(acc[1], S[1]); }
+            else { v0 = acc[0] / S[0]; v1 = acc[1] / S[1]; }
+            store2(og + SLOT * s, lane16, v0, v1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (PF == 0) {
+        for (; u + ustride < n_units; u += ustride) process(std::true_type{}, u, RA);
+        process(std::false_type{}, u, RA);
+    } else {
+        while (true) {                                                               // RA holds unit u
+            if (u + ustride >= n_units) { process(std::false_type{}, u, RA); break; }
+            load_unit(u + ustride, RB);
+            __builtin_amdgcn_sched_barrier(0);
+            process(std::false_type{}, u, RA);
+            u += ustride;                                                            // RB holds unit u
+            if (u + ustride >= n_units) { process(std::false_type{}, u, RB); break; }
+            load_unit(u + ustride, RA);
+            __builtin_amdgcn_sched_barrier(0);
+            process(std::false_type{}, u, RB);
+            u += ustride;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1112,6 +1328,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HM_F64_STD_
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// hm_merge_describe(): the dispatch below runs with this pointer set and every launch site records its kernel's name
+// instead of launching - so the description cannot drift from what hm_merge really dispatches to.
+static thread_local std::string* g_describe = nullptr;
+static bool describe_only(const char* fmt, int a = 0, int b = 0, int c = 0, int d = 0) {
+    if (!g_describe) return false;
+    char buf[160];
+    snprintf(buf, sizeof buf, fmt, a, b, c, d);
+    if (!g_describe->empty()) *g_describe += " + ";
+    *g_describe += buf;
+    return true;
+}
+
 static int g_cu_count = 0;
 int cu_count() {
     if (g_cu_count == 0) {
@@ -1148,6 +1376,9 @@ static bool decode_variant(int variant, bool with_std, FastCfg& c) {
         c.u = u; c.prefetch = pf;
         return true;
     }
+#ifndef HM_PROBE
+    if (tab == TAB_NONE) return false;                // the table-free traffic probe (wrong results) exists in -DHM_PROBE builds only
+#endif
     if ((tab != TAB_PLAIN && tab != TAB_FUSED && tab != TAB_NONE) || pf > 1 || (u != 2 && u != 4 && u != 8) || bc > 1) return false;
     c.tab = tab; c.u = u; c.prefetch = pf; c.block = bc ? 1024 : 256;
     return true;
@@ -1159,6 +1390,7 @@ static int launch_one(const MergeK& k, hipStream_t st) {
     void (*kernel)(const MergeK);
     if constexpr (STD) kernel = merge_u8_fast_std<NF, U, TAB, PF, FLAT, SUMW, BLOCK>;
     else kernel = merge_u8_fast<NF, U, TAB, false, PF, FLAT, SUMW, BLOCK>;
+    if (describe_only(STD ? "merge_u8_fast_std<N=%d,U=%d,flat=%d,sum_w=%d>" : "merge_u8_fast<N=%d,U=%d,flat=%d,sum_w=%d>", NF, U, FLAT, SUMW)) return HM_OK;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
     const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
@@ -1171,6 +1403,53 @@ static int launch_one(const MergeK& k, hipStream_t st) {
 #define HM_TUNE_NF 0      /* build with -DHM_TUNE_NF=7 to get the variant matrix for N = 7 */
 #endif
 
+// the val-only, no-extras configuration runs merge_u8_val3 unless a variant asks for the older merge_u8_fast (A/B runs).
+// variant 7UPM (tuning builds, N == HM_TUNE_NF only) selects merge_u8_val3<NF, U, PF, MAP>; 0 = the production choice.
+struct Val3Cfg { int u, pf, map; };
+constexpr Val3Cfg kVal3Default = {2, 1, 0};     // A/B on one box (profiles/r02_ab_val3_matrix2.json): 125.5 us against 130.0 us for merge_u8_fast and 133-135 us for the in-place refill
+static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
+    c = kVal3Default;
+    if (variant == 0) return true;
+    if (variant < 7000 || variant >= 8000 || n_frames != HM_TUNE_NF) return false;
+    c.u = (variant / 100) % 10; c.pf = (variant / 10) % 10; c.map = variant % 10;
+    return (c.u == 2 || c.u == 3) && c.pf <= 1 && c.map <= 1;
+}
+static bool use_val3(int variant, int n_frames, bool with_std, bool extras) {
+    Val3Cfg c;
+    return !with_std && !extras && val3_variant(variant, n_frames, c);
+}
+static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map ? 4 : 1) * static_cast<int>(kSub); }
+
+template <int NF, int U, int PF, int MAP>
+static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
+    const int64_t units = k.n_elems / (U * (MAP ? 4 : 1) * static_cast<int>(kSub));
+    unsigned grid = MAP ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, 8);   // 8 workgroups of 4 waves per CU
+    if (U % 3 != 0 && grid >= 3) grid -= grid % 3;          // the unit index must advance by a multiple of 3 per iteration (see the kernel)
+    if (grid == 0) grid = 1;
+    if (describe_only("merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;
+    hipLaunchKernelGGL((merge_u8_val3<NF, U, PF, MAP>), dim3(grid), dim3(256), 0, st, k);
+    return launch_status();
+}
+template <int NF>
+static int launch_val3(const MergeK& k, hipStream_t st) {
+    Val3Cfg c;
+    if (!val3_variant(k.variant, NF, c)) return HM_EINVAL;
+    if constexpr (NF == HM_TUNE_NF) {
+        switch (c.u * 100 + c.pf * 10 + c.map) {
+            case 300: return launch_val3_cfg<NF, 3, 0, 0>(k, st);
+            case 301: return launch_val3_cfg<NF, 3, 0, 1>(k, st);
+            case 310: return launch_val3_cfg<NF, 3, 1, 0>(k, st);
+            case 311: return launch_val3_cfg<NF, 3, 1, 1>(k, st);
+            case 200: return launch_val3_cfg<NF, 2, 0, 0>(k, st);
+            case 201: return launch_val3_cfg<NF, 2, 0, 1>(k, st);
+            case 210: return launch_val3_cfg<NF, 2, 1, 0>(k, st);
+            default:  return launch_val3_cfg<NF, 2, 1, 1>(k, st);
+        }
+    } else {
+        return launch_val3_cfg<NF, kVal3Default.u, kVal3Default.pf, kVal3Default.map>(k, st);
+    }
+}
+
 template <int NF, int U, int TAB, bool PF>
 static int launch_val_blk(const MergeK& k, const FastCfg& c, hipStream_t st) {
     if (c.block == 256) return launch_one<NF, U, TAB, false, PF, false, false, 256>(k, st);
@@ -1182,7 +1461,11 @@ static int launch_val_tab(const MergeK& k, const FastCfg& c, hipStream_t st) {
     switch (c.tab) {
         case TAB_PLAIN: return launch_val_blk<NF, U, TAB_PLAIN, PF>(k, c, st);
         case TAB_FUSED: return launch_val_blk<NF, U, TAB_FUSED, PF>(k, c, st);
+#ifdef HM_PROBE
         default:        return launch_val_blk<NF, U, TAB_NONE, PF>(k, c, st);
+#else
+        default:        return HM_EINVAL;
+#endif
     }
 }
 
@@ -1212,6 +1495,7 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
         return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256>(k, st);
     }
     if (extras) return launch_extras<NF, false, kUVal, TAB_FUSED>(k, st);
+    if (use_val3(k.variant, NF, false, false)) return launch_val3<NF>(k, st);
     if constexpr (NF == HM_TUNE_NF) {
         if (c.prefetch) {
             if (c.u == 2) return launch_val_tab<NF, 2, true>(k, c, st);
@@ -1227,7 +1511,8 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
 }
 
 // elements per group of the configuration launch_fast_nf() will really use
-static int fast_group_elems(int n_frames, const FastCfg& c, bool with_std, bool extras) {
+static int fast_group_elems(int n_frames, int variant, const FastCfg& c, bool with_std, bool extras) {
+    { Val3Cfg vc; if (!with_std && !extras && val3_variant(variant, n_frames, vc)) return val3_unit_elems(vc); }
     if (with_std) return ((extras || n_frames != HM_TUNE_NF) ? kUStd : c.u) * static_cast<int>(kSub);
     if (extras || n_frames != HM_TUNE_NF) return kUVal * static_cast<int>(kSub);
     return c.u * static_cast<int>(kSub);
@@ -1238,6 +1523,7 @@ static int launch_loop_c(const MergeK& k, bool with_std, hipStream_t st) {
     const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
     const int lds = (with_std ? 16 * 256 + 16 * 256 * C : 16 * 256 * C) + (flat ? 16 * 256 : 0);
     const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
+    if (describe_only(with_std ? "merge_u8_loop_std<C=%d,flat=%d,sum_w=%d>(N=%d)" : "merge_u8_loop<C=%d,flat=%d,sum_w=%d>(N=%d)", C, flat, sumw, k.n_frames)) return HM_OK;
 #define HM_LOOP(K, F, W) hipLaunchKernelGGL((K<C, F, W>), dim3(grid), dim3(256), lds, st, k)
     if (with_std) {
         if (flat && sumw) HM_LOOP(merge_u8_loop_std, true, true); else if (flat) HM_LOOP(merge_u8_loop_std, true, false);
@@ -1255,6 +1541,7 @@ static int launch_f64_c(const MergeK& k, bool with_std, hipStream_t st) {
     const bool flat = k.has_flat != 0, sumw = k.out_sum_w != nullptr;
     const int lds = 16 * 256 * C + (flat ? 16 * 256 : 0);
     const unsigned grid = stream_grid(k.n_elems / static_cast<int>(kSub), 4, 8);
+    if (describe_only(with_std ? "merge_f64_std<C=%d,flat=%d,sum_w=%d>(N=%d)" : "merge_f64_val<C=%d,flat=%d,sum_w=%d>(N=%d)", C, flat, sumw, k.n_frames)) return HM_OK;
 #define HM_F64(K, F, W) hipLaunchKernelGGL((K<C, F, W>), dim3(grid), dim3(256), lds, st, k)
     if (with_std) {
         if (flat && sumw) HM_F64(merge_f64_std, true, true); else if (flat) HM_F64(merge_f64_std, true, false);
@@ -1287,6 +1574,7 @@ static int launch_loop(const MergeK& k, bool with_std, hipStream_t st) {
 
 static int launch_generic(const MergeK& k, bool f64in, bool with_std, hipStream_t st) {
     const unsigned grid = stream_grid(k.n_elems, 256, 8);
+    if (describe_only("merge_generic<f64in=%d,std=%d>", f64in, with_std)) return HM_OK;
 #define HM_GEN(F, S) hipLaunchKernelGGL((merge_generic<F, S>), dim3(grid), dim3(256), 0, st, k)
     if (f64in) { if (with_std) HM_GEN(true, true); else HM_GEN(true, false); }
     else       { if (with_std) HM_GEN(false, true); else HM_GEN(false, false); }
@@ -1297,6 +1585,7 @@ static int launch_generic(const MergeK& k, bool f64in, bool with_std, hipStream_
 static int launch_fixup(const MergeK& k, bool f64in, bool with_std, hipStream_t st) {
     const int64_t chunks = (k.n_elems + 15) / 16;
     const unsigned grid = stream_grid(chunks, 256, 8);
+    if (describe_only("merge_fixup_hot<f64in=%d,std=%d>", f64in, with_std)) return HM_OK;
 #define HM_FIX(F, S) hipLaunchKernelGGL((merge_fixup_hot<F, S>), dim3(grid), dim3(256), 0, st, k)
     if (f64in) { if (with_std) HM_FIX(true, true); else HM_FIX(true, false); }
     else       { if (with_std) HM_FIX(false, true); else HM_FIX(false, false); }
@@ -1319,6 +1608,16 @@ extern "C" int64_t hm_merge_algorithmic_bytes(const hm_merge_args* g) {
     if (g->darks_u8)
         for (int i = 0; i < N; ++i) per += g->darks_u8[i] ? 1 : 0;
     return per * E;
+}
+
+extern "C" int hm_merge_describe(const hm_merge_args* g, char* buf, int buf_len) {
+    if (!buf || buf_len < 1) return HM_EINVAL;
+    std::string names;
+    hm::g_describe = &names;
+    const int rc = hm_merge(g, nullptr);
+    hm::g_describe = nullptr;
+    snprintf(buf, static_cast<size_t>(buf_len), "%s", names.c_str());
+    return rc;
 }
 
 extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
@@ -1385,11 +1684,18 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     k.in_off = (g->row0 - g->buf_row0) * g->width * C;
     k.H = g->height; k.W = g->width; k.row0 = g->row0; k.buf_row0 = g->buf_row0; k.buf_rows = g->buf_rows;
     k.n_frames = N; k.C = C; k.median_k = hot ? g->median_k : 3; k.has_flat = flat ? 1 : 0;
+    k.variant = g->variant;
+    k.inv_t_inrange = 1;
+    for (int i = 0; i < N; ++i) k.inv_t_inrange = k.inv_t_inrange && k.inv_t[i] >= 0x1p-300 && k.inv_t[i] <= 0x1p300;
     hipStream_t st = as_stream(stream);
 
     // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
-    if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
+    if (g->variant >= 7000 && g->variant < 8000) {            // merge_u8_val3 A/B variants (tuning builds)
+        Val3Cfg vc;
+        if (!val3_variant(g->variant, N, vc) || with_std || flat || g->out_sum_w || f64in || C != 3) return HM_EINVAL;
+        cfg = default_cfg(with_std);
+    } else if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
     bool fast = g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
     const bool loop_kernel = f64in || N > 16 || C != 3;         // run-time-N / any-C streaming kernel instead of the N <= 16, C = 3 templates
     if (fast) {
@@ -1407,7 +1713,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (!fast) {
         rc = launch_generic(k, f64in, with_std, st);
     } else {
-        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : fast_group_elems(N, cfg, with_std, flat || g->out_sum_w);
+        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : fast_group_elems(N, g->variant, cfg, with_std, flat || g->out_sum_w);
         const int64_t body = (E / grp) * grp;
         if (body > 0) {
             MergeK kb = k;

@@ -83,9 +83,125 @@ __global__ __launch_bounds__(256) void k_unary(int op, const double* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// x ** p for a plain scalar exponent p (no uncertainty of its own) - Measurand.__pow__, modules/measurand.py:217-241, as the
+// merge loop uses it (S ** 2 at exposure_series.py:343, ** (1/2) at :394). The generic kernel above evaluates pow() twice and
+// log() once per element (0.19 of the HBM roofline, profiles/r01e_bench_ops.json); with the exponent known on the host
+//   value:  p == 2 -> x*x,  p == 0.5 -> sqrt(x),  p == 1 -> x,  small integer p -> repeated multiplication, else pow(x, p)
+//   std  :  |dx**p/dx| * s = (p * x**(p-1)) * s, with x**(p-1) = x, 1/sqrt(x)... formed from the value; the exponent's term
+//           (ln x * x**p * 0)**2 of :236-239 is +0 whenever ln x * x**p is finite and is evaluated as written otherwise
+//           (x <= 0 or non-finite: NumPy gives NaN / inf there and so does this kernel).
+// Results agree with NumPy's pow-based evaluation to a few ulp (tests hold 1e-13 against the reference's own outputs).
+// Two elements per lane, 16-byte accesses.
+// ------------------------------------------------------------------------------------------------
+enum { POW_SQUARE = 0, POW_SQRT = 1, POW_ONE = 2, POW_INT = 3, POW_GENERAL = 4 };
+
+template <int KIND>
+__device__ __forceinline__ void pow_scalar_eval(double x, double s, double p, int ip, bool with_std, double& r, double& rs) {
+    double d;                                               // x ** (p - 1)
+    if (KIND == POW_SQUARE) { r = x * x; d = x; }
+    else if (KIND == POW_SQRT) { r = sqrt(x); d = 1.0 / r; }
+    else if (KIND == POW_ONE) { r = x; d = 1.0; }
+    else if (KIND == POW_INT) {                             // |ip| <= 8: x**(|ip|-1) by multiplication, one more for the value
+        const int n = ip < 0 ? -ip : ip;
+        double acc = 1.0;
+        for (int k = 1; k < n; ++k) acc *= x;
+        if (ip > 0) { d = acc; r = acc * x; }
+        else { r = 1.0 / (acc * x); d = r / x; }
+    } else { r = pow(x, p); d = pow(x, p - 1.0); }
+    if (with_std) {
+        const double a = (p * d) * s;                        // measurand.py:236
+        double b = 0.0;                                      // (log(x1) * x1**x2) * 0, :237-238
+        const double lr = r;
+        if (!(x > 0.0) || !(fabs(x) < __builtin_huge_val()) || !(fabs(lr) < __builtin_huge_val())) b = (log(x) * r) * 0.0;
+        rs = sqrt(a * a + b * b);
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pow_scalar(const double* __restrict__ x, const double* __restrict__ s, double* __restrict__ out,
+                                                    double* __restrict__ out_s, int64_t n, double p, int ip) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const bool with_std = out_s != nullptr;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t pairs = n / 2;
+    const bool vec = aligned_dev(x, 16) && aligned_dev(out, 16) && (!with_std || (aligned_dev(s, 16) && aligned_dev(out_s, 16)));
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < pairs; q += stride) {
+        double x0, x1, s0 = 0.0, s1 = 0.0;
+        if (vec) {
+            const f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x) + q);
+            x0 = v.x; x1 = v.y;
+            if (with_std) { const f64x2 u = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s) + q); s0 = u.x; s1 = u.y; }
+        } else {
+            x0 = x[2 * q]; x1 = x[2 * q + 1];
+            if (with_std) { s0 = s[2 * q]; s1 = s[2 * q + 1]; }
+        }
+        double r0, r1, e0 = 0.0, e1 = 0.0;
+        pow_scalar_eval<KIND>(x0, s0, p, ip, with_std, r0, e0);
+        pow_scalar_eval<KIND>(x1, s1, p, ip, with_std, r1, e1);
+        if (vec) {
+            f64x2 o; o.x = r0; o.y = r1;
+            __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(out) + q);
+            if (with_std) { f64x2 e; e.x = e0; e.y = e1; __builtin_nontemporal_store(e, reinterpret_cast<f64x2*>(out_s) + q); }
+        } else {
+            out[2 * q] = r0; out[2 * q + 1] = r1;
+            if (with_std) { out_s[2 * q] = e0; out_s[2 * q + 1] = e1; }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double r, e = 0.0;
+        pow_scalar_eval<KIND>(x[n - 1], with_std ? s[n - 1] : 0.0, p, ip, with_std, r, e);
+        out[n - 1] = r;
+        if (with_std) out_s[n - 1] = e;
+    }
+}
+
+// take along one axis: out[o, k, i] = in[o, idx[k], i] for the (outer, axis_len, inner) view of a dense array
+// (modules/measurand.py:352-373, lib.take(val, dims, axis)). A pure gather copy: val and std in one launch.
+struct TakeK {
+    int64_t idx[HM_TAKE_MAX];
+    int n_idx;
+};
+__global__ __launch_bounds__(256) void k_take(const double* __restrict__ x, const double* __restrict__ s, double* __restrict__ out,
+                                              double* __restrict__ out_s, int64_t outer, int64_t axis_len, int64_t inner, const TakeK t) {
+    const int64_t n = outer * t.n_idx * inner;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int64_t i = e % inner;
+        const int64_t r = e / inner;
+        const int64_t kx = r % t.n_idx;
+        const int64_t o = r / t.n_idx;
+        int64_t src_k = t.idx[0];
+        for (int q = 1; q < t.n_idx; ++q) src_k = kx == q ? t.idx[q] : src_k;       // uniform indexing of the kernarg array
+        const int64_t src = (o * axis_len + src_k) * inner + i;
+        out[e] = x[src];
+        if (out_s) out_s[e] = s[src];
+    }
+}
+
 }  // namespace hm
 
 using namespace hm;
+
+extern "C" int hm_take_axis(const double* x, const double* s, double* out_val, double* out_std, int64_t outer, int64_t axis_len,
+                            int64_t inner, const int64_t* indices, int n_indices, void* stream) {
+    if (!x || !out_val || !indices || outer < 0 || axis_len < 1 || inner < 1 || n_indices < 1) return HM_EINVAL;
+    if (n_indices > HM_TAKE_MAX) return HM_EUNSUPPORTED;
+    if ((out_std != nullptr) != (s != nullptr)) return HM_EINVAL;
+    TakeK t{};
+    t.n_idx = n_indices;
+    for (int q = 0; q < n_indices; ++q) {
+        int64_t v = indices[q];
+        if (v < 0) v += axis_len;                          // NumPy's negative indices
+        if (v < 0 || v >= axis_len) return HM_ESHAPE;      // np.take raises IndexError (mode='raise')
+        t.idx[q] = v;
+    }
+    const int64_t n = outer * n_indices * inner;
+    if (n == 0) return HM_OK;
+    hipLaunchKernelGGL(k_take, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), x, s, out_val, out_std, outer, axis_len, inner, t);
+    return launch_status();
+}
 
 extern "C" int hm_binary_op(int op, const double* x1, const double* s1, const double* x2, const double* s2,
                             double* out_val, double* out_std, int ndim, const int64_t* shape,
@@ -128,5 +244,24 @@ extern "C" int hm_unary_op(int op, const double* x, const double* s, double* out
     if (!x || !out_val || ((out_std != nullptr) != (s != nullptr))) return HM_EINVAL;
     if (!aligned(x, 8) || !aligned(out_val, 8)) return HM_EALIGN;
     hipLaunchKernelGGL(k_unary, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), op, x, s, out_val, out_std, n);
+    return launch_status();
+}
+
+extern "C" int hm_pow_scalar(const double* x, const double* s, double exponent, double* out_val, double* out_std, int64_t n, void* stream) {
+    if (n < 0) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!x || !out_val || ((out_std != nullptr) != (s != nullptr))) return HM_EINVAL;
+    if (!aligned(x, 8) || !aligned(out_val, 8)) return HM_EALIGN;
+    const unsigned grid = stream_grid((n + 1) / 2, 256, 8);
+    hipStream_t st = as_stream(stream);
+    const double p = exponent;
+    const int ip = (p == static_cast<double>(static_cast<int>(p)) && p >= -8.0 && p <= 8.0) ? static_cast<int>(p) : 0;
+#define HM_POW(K) hipLaunchKernelGGL(k_pow_scalar<K>, dim3(grid), dim3(256), 0, st, x, s, out_val, out_std, n, p, ip)
+    if (p == 2.0) HM_POW(POW_SQUARE);
+    else if (p == 0.5) HM_POW(POW_SQRT);
+    else if (p == 1.0) HM_POW(POW_ONE);
+    else if (ip != 0) HM_POW(POW_INT);
+    else HM_POW(POW_GENERAL);
+#undef HM_POW
     return launch_status();
 }

@@ -405,16 +405,41 @@ __global__ __launch_bounds__(64) void k_minmax_final(const double* __restrict__ 
     out[2 * k] = a; out[2 * k + 1] = b;
 }
 
+// apply_thresholds for more than HM_MAX_CHANNELS channels on the last axis (the reference's property tests draw up to 10):
+// limits staged in LDS (uniform loop over the kernarg arrays), one element per thread.
+struct ChanLimitsWide { double lo[HM_THRESHOLD_MAX_CHANNELS]; double hi[HM_THRESHOLD_MAX_CHANNELS]; };
+__global__ __launch_bounds__(256) void k_thresholds_wide(double* __restrict__ val, double* __restrict__ sd, const ChanLimitsWide lim,
+                                                         int64_t n, int C) {
+    __shared__ double lo[HM_THRESHOLD_MAX_CHANNELS], hi[HM_THRESHOLD_MAX_CHANNELS];
+    for (int k = 0; k < C; ++k)
+        if (threadIdx.x == 0) { lo[k] = lim.lo[k]; hi[k] = lim.hi[k]; }
+    __syncthreads();
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int c = static_cast<int>(e % C);
+        const double v = val[e];
+        if ((v < lo[c]) || (v > hi[c])) { val[e] = nan; if (sd) sd[e] = nan; }       // measurand.py:418
+    }
+}
+
 }  // namespace hm
 
 using namespace hm;
 
 extern "C" int hm_apply_thresholds(double* val, double* std, const double* lower, const double* upper,
                                    int64_t n, int C, void* stream) {
-    if (n < 0 || C < 1 || C > HM_MAX_CHANNELS || !lower || !upper) return HM_EINVAL;
+    if (n < 0 || C < 1 || !lower || !upper) return HM_EINVAL;
+    if (C > HM_THRESHOLD_MAX_CHANNELS) return HM_EUNSUPPORTED;
     if (n == 0) return HM_OK;
     if (!val) return HM_EINVAL;
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
+    if (C > HM_MAX_CHANNELS) {
+        ChanLimitsWide w{};
+        for (int c = 0; c < C; ++c) { w.lo[c] = lower[c]; w.hi[c] = upper[c]; }
+        hipLaunchKernelGGL(k_thresholds_wide, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), val, std, w, n, C);
+        return launch_status();
+    }
     ChanLimits lim{};
     for (int c = 0; c < C; ++c) { lim.lo[c] = lower[c]; lim.hi[c] = upper[c]; }
     hipLaunchKernelGGL(k_thresholds, dim3(stream_grid((n + 1) / 2, 256, 8)), dim3(256), 0, as_stream(stream), val, std, lim, n, C);

@@ -263,6 +263,13 @@ class MergePlan:
     def algorithmic_bytes(self) -> int:
         return int(nat.lib.hm_merge_algorithmic_bytes(C.byref(self.args)))
 
+    @property
+    def kernels(self) -> str:
+        """Names of the kernels launch() dispatches to, in launch order (hm_merge_describe: the library's own dispatch, dry)."""
+        buf = C.create_string_buffer(512)
+        nat.check(nat.lib.hm_merge_describe(self._ref, buf, 512), "hm_merge_describe")
+        return buf.value.decode()
+
 
 def plan_merge(frames: Sequence[torch.Tensor], exposures: Sequence[float], icrf, icrf_diff=None,
                stds: Optional[Sequence[torch.Tensor]] = None,
@@ -468,6 +475,19 @@ def elementwise_binary(op: int, x1: torch.Tensor, s1, x2: torch.Tensor, s2):
     return out, out_std
 
 
+def pow_scalar(x: torch.Tensor, s: Optional[torch.Tensor], exponent: float):
+    """modules/measurand.py:217-241 for a plain scalar exponent -> (val, std | None); hm_pow_scalar (no pow() for 2, 0.5, 1, small integers)."""
+    _require_cuda(x, "val")
+    x = x.contiguous()
+    s = None if s is None else s.to(_F64).contiguous()
+    out = torch.empty_like(x)
+    out_s = None if s is None else torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.hm_pow_scalar(x.data_ptr(), nat.ptr(s), float(exponent), out.data_ptr(), nat.ptr(out_s), x.numel(),
+                                        _stream(x.device)), "hm_pow_scalar")
+    return out, out_s
+
+
 def elementwise_unary(op: int, x: torch.Tensor, s):
     _require_cuda(x, "x")
     x = x.to(_F64).contiguous()
@@ -484,6 +504,33 @@ def elementwise_unary(op: int, x: torch.Tensor, s):
 # ---------------------------------------------------------------------------------------------
 # linearity statistics
 # ---------------------------------------------------------------------------------------------
+def take_axis(x: torch.Tensor, s: Optional[torch.Tensor], indices: Sequence[int], axis: Optional[int]):
+    """modules/measurand.py:352-373 (`lib.take(val, dims, axis)`): axis=None indexes the flattened array."""
+    _require_cuda(x, "val")
+    x = x.contiguous()
+    if s is not None:
+        _require_cuda(s, "std")
+        s = s.to(_F64).contiguous()
+    idx = [int(i) for i in indices]
+    if axis is None:
+        outer, axis_len, inner, out_shape = 1, x.numel(), 1, (len(idx),)
+    else:
+        ax = axis % x.dim()
+        outer = int(np.prod(x.shape[:ax], dtype=np.int64))
+        inner = int(np.prod(x.shape[ax + 1:], dtype=np.int64))
+        axis_len = x.shape[ax]
+        out_shape = tuple(x.shape[:ax]) + (len(idx),) + tuple(x.shape[ax + 1:])
+    if any(i < -axis_len or i >= axis_len for i in idx):
+        raise IndexError(f"index out of bounds for axis of size {axis_len}")
+    out = torch.empty(out_shape, dtype=_F64, device=x.device)
+    out_s = None if s is None else torch.empty(out_shape, dtype=_F64, device=x.device)
+    arr = (C.c_int64 * len(idx))(*idx)
+    with torch.cuda.device(x.device):
+        nat.check(nat.lib.hm_take_axis(x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_s), outer, axis_len, inner,
+                                       arr, len(idx), _stream(x.device)), "hm_take_axis")
+    return out, out_s
+
+
 def apply_thresholds_(val: torch.Tensor, std: Optional[torch.Tensor], lower: Sequence[float], upper: Sequence[float]) -> None:
     """modules/measurand.py:375-428, in place on contiguous float64 device tensors (last axis = channels)."""
     _require_cuda(val, "val")

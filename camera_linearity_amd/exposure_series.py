@@ -192,7 +192,7 @@ class ExposureSeries(object):
         if list_of_dark_fields:
             darks, mins = [], []
             for s in sets:
-                dark, scale = s.select_dark_field(list_of_dark_fields, thr)
+                dark, scale = s.select_dark_field(list_of_dark_fields)    # exposure gate: gs.DARK_THRESHOLD (image_set.py:173); `thr` is the PIXEL threshold (:387)
                 if dark is None:
                     darks.append(None)
                     mins.append(gs.BITS)
@@ -222,10 +222,14 @@ class ExposureSeries(object):
         from . import engine
         sets = self.input_image_sets
         if use_std is None:
-            for s in sets:                                  # the reference loads every frame's std image (:377)
-                if s.measurand.std is None and s.path is not None and s.measurand.shape is None:
+            for s in sets:                                  # the reference loads every frame's std image (:377),
+                if s.measurand.std is None and s.path is not None:     # whether or not its value image is in memory yet
                     s.load_std_image()
-            use_std = all(s.measurand.std is not None for s in sets)
+            have = [s.measurand.std is not None for s in sets]
+            if any(have) and not all(have):
+                raise ValueError("some frames have a std image and some do not: uncertainty propagation needs one for every frame "
+                                 "(pass use_std=False to merge values only)")
+            use_std = all(have)
         frames, stds, darks, mins = self._stack_inputs(list_of_dark_fields, dark_threshold, with_std=use_std)
         if ICRF_diff is None and use_std:
             ICRF_diff = icrf_derivative(ICRF)
@@ -256,11 +260,25 @@ class ExposureSeries(object):
 
     def process_HDR_image(self, ICRF=None, ICRF_diff=None, dark_list: Optional[List[ImageSet]] = None,
                           flat_list: Optional[List[ImageSet]] = None, use_std: Optional[bool] = None):
-        """exposure_series.py:399-419: merge the input images into self.merged_image_set."""
+        """exposure_series.py:399-419: merge the input images into self.merged_image_set.
+
+        Defaults mirror the reference: `ICRF=None` reads settings.ICRF_CALIBRATED_FILE (:406-407; deviation E - the table is
+        read as ONE (BITS, C) array and the derivative is formed with the reference's gradient convention), `dark_list=None`
+        globs settings.DEFAULT_DARK_PATH (:409) and `flat_list=None` settings.DEFAULT_FLAT_PATH (image_set.py:146-155). A
+        path that is not configured means "none": no dark frames / no flat field - but a missing ICRF raises."""
         if ICRF is None:
-            raise ValueError("process_HDR_image needs the ICRF array (there is no config-file default in this package)")
+            if gs.ICRF_CALIBRATED_FILE is None:
+                raise ValueError("process_HDR_image(ICRF=None) needs settings.ICRF_CALIBRATED_FILE (settings.configure(...)) "
+                                 "or an explicit ICRF array")
+            ICRF, default_diff = read_ICRF_file(gs.ICRF_CALIBRATED_FILE)
+            if ICRF_diff is None:
+                ICRF_diff = default_diff
         if not self.input_image_sets:
             raise ValueError("no input images")
+        if dark_list is None and gs.DEFAULT_DARK_PATH is not None:
+            dark_list = ImageSet.multiple_from_path(Path(gs.DEFAULT_DARK_PATH))
+        if flat_list is None and gs.DEFAULT_FLAT_PATH is not None:
+            flat_list = ImageSet.multiple_from_path(Path(gs.DEFAULT_FLAT_PATH))
         flat_set = self.input_image_sets[0].get_flat_field(flat_list) if flat_list else None
         self.merged_image_set = self._compute_HDR_image_set(dark_list, None, None, ICRF, ICRF_diff, flat_set=flat_set,
                                                             use_std=use_std)

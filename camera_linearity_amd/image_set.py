@@ -121,7 +121,9 @@ class ImageSet(object):
         return True
 
     def get_flat_field(self, list_of_flat_fields: Optional[List["ImageSet"]] = None):
-        """image_set.py:146-155 (the list must be given: there is no config-file default path here)."""
+        """image_set.py:146-155. `None` globs settings.DEFAULT_FLAT_PATH when that is configured (else: no flat field)."""
+        if list_of_flat_fields is None and gs.DEFAULT_FLAT_PATH is not None:
+            list_of_flat_fields = ImageSet.multiple_from_path(Path(gs.DEFAULT_FLAT_PATH))
         if list_of_flat_fields is None or self.features is None:
             return None
         for flat_set in list_of_flat_fields:
@@ -133,6 +135,8 @@ class ImageSet(object):
     def select_dark_field(self, list_of_dark_fields: Optional[List["ImageSet"]], dark_threshold: Optional[float] = None):
         """The selection rule of get_dark_field (image_set.py:171-198) without touching pixels:
         returns (dark ImageSet, scale) or (None, 0.0). scale = target/dark exposure (deviation I)."""
+        if list_of_dark_fields is None and gs.DEFAULT_DARK_PATH is not None:      # image_set.py:169-170
+            list_of_dark_fields = ImageSet.multiple_from_path(Path(gs.DEFAULT_DARK_PATH))
         if not list_of_dark_fields:
             return None, 0.0
         thr = gs.DARK_THRESHOLD if dark_threshold is None else dark_threshold

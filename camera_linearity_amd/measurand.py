@@ -244,6 +244,11 @@ class HipMeasurand(AbstractMeasurand):
 
     def __pow__(self, other):
         from ._native import HM_OP_POW
+        if isinstance(other, (int, float)) and not isinstance(other, bool):
+            # plain scalar exponent (S ** 2, ** (1/2) of the merge loop): the propagation formula of measurand.py:236-239 with
+            # s2 = 0, value and derivative without pow() where the exponent allows (hm_pow_scalar)
+            val, std = _engine().pow_scalar(self._f64(), self.std, float(other))
+            return self.__class__(val, std)
         return self._binary(other, HM_OP_POW)
 
     def _unary(self, op):
@@ -316,13 +321,12 @@ class HipMeasurand(AbstractMeasurand):
         val, std = eng.normalize_by_map(self._f64(), self.std, fval, map.std, means, std_means)
         return self.__class__(val, std)
 
-    # ---------------------------------------------------------------- "next" rows (torch device ops)
+    # ---------------------------------------------------------------- "next" rows: every branch below is one HIP kernel of
+    # libhdrmerge or an explicit error - there are no torch arithmetic fallbacks (tests/test_gpu_api.py asserts which symbol ran)
     def extract(self, dims=None, axis: Optional[int] = None):
-        """modules/measurand.py:352-373."""
-        target = [dims] if type(dims) is int else dims
-        idx = torch.as_tensor(target, device=self.val.device)
-        value = torch.index_select(self.val, axis if axis is not None else 0, idx)
-        std = None if self.std is None else torch.index_select(self.std, axis if axis is not None else 0, idx)
+        """modules/measurand.py:352-373: lib.take(val, dims, axis); axis=None indexes the flattened array (hm_take_axis)."""
+        target = [dims] if type(dims) is int else list(dims)
+        value, std = _engine().take_axis(self._f64(), self.std, target, axis)
         return self.__class__(value, std)
 
     def apply_thresholds(self, lower: Optional[List] = None, upper: Optional[List] = None):
@@ -335,42 +339,30 @@ class HipMeasurand(AbstractMeasurand):
             raise ValueError("The length of 'lower' and 'upper' must match the size of the independent axis.")
         lo_l = [l if l is not None else -math.inf for l in lower]
         hi_l = [u if u is not None else math.inf for u in upper]
-        if value.is_cuda and n <= 4:
-            value = value.contiguous()
-            if self._std is not None and not self._std.is_contiguous():
-                self._std = self._std.contiguous()
-            _engine().apply_thresholds_(value, self._std, lo_l, hi_l)          # hm_apply_thresholds, in place
-            self.val = value
-            return
-        lo = torch.tensor(lo_l, dtype=_F64, device=value.device)
-        hi = torch.tensor(hi_l, dtype=_F64, device=value.device)
-        mask = (value < lo) | (value > hi)
-        value[mask] = math.nan
+        if not value.is_cuda:
+            raise RuntimeError("apply_thresholds needs the image on the device (there is no CPU fallback)")
+        if n > 32:
+            raise NotImplementedError("hm_apply_thresholds supports up to 32 channels on the last axis")
+        value = value.contiguous()
+        if self._std is not None and not self._std.is_contiguous():
+            self._std = self._std.contiguous()
+        _engine().apply_thresholds_(value, self._std, lo_l, hi_l)          # hm_apply_thresholds, in place
         self.val = value
-        if self.std is not None:
-            self._std[mask] = math.nan
 
     def compute_dimension_statistics(self, axis=None):
         """modules/measurand.py:318-350."""
         values = self._f64()
-        all_but_last = axis is not None and values.dim() >= 2 and \
+        if not values.is_cuda:
+            raise RuntimeError("compute_dimension_statistics needs the image on the device (there is no CPU fallback)")
+        if axis is None:                                                         # statistics over every element: one "channel"
+            st = _engine().channel_statistics(values.reshape(-1, 1), None if self.std is None else self.std.reshape(-1, 1))
+            return {k_: (None if v is None else v.reshape(())) for k_, v in st.items()}
+        all_but_last = values.dim() >= 2 and \
             sorted(a % values.dim() for a in ((axis,) if isinstance(axis, int) else tuple(axis))) == list(range(values.dim() - 1))
-        if values.is_cuda and all_but_last and values.shape[-1] <= 4:
+        if all_but_last and values.shape[-1] <= 4:
             return _engine().channel_statistics(values, self.std)                # hm_channel_statistics
-        if self.std is None:
-            mean = torch.nanmean(values, dim=axis) if axis is not None else torch.nanmean(values)
-            cnt = (~torch.isnan(values)).sum(dim=axis) if axis is not None else (~torch.isnan(values)).sum()
-            dev = torch.nan_to_num(values - (mean if axis is None else mean.reshape(_keep(values, axis))), nan=0.0)
-            sd = torch.sqrt((dev ** 2).sum(dim=axis) / cnt) if axis is not None else torch.sqrt((dev ** 2).sum() / cnt)
-            return {"mean": mean, "std": sd, "error": None}
-        weights = 1 / self.std
-        kw = {} if axis is None else {"dim": axis}
-        sw = torch.nansum(weights, **kw)
-        mean = torch.nansum(values * weights, **kw) / sw
-        mb = mean if axis is None else mean.reshape(_keep(values, axis))
-        sd = torch.sqrt(torch.nansum(weights * (values - mb) ** 2, **kw) / sw)
-        err = torch.nanmean(self.std, **kw)
-        return {"mean": mean, "std": sd, "error": err}
+        raise NotImplementedError("hm_channel_statistics reduces over all axes (axis=None) or over all but the last axis of an "
+                                  "array with at most 4 channels (axis=(0, 1) of an image) - the two cases the reference uses")
 
     def compute_kernel_density_estimate(self, data_points: int, included_range=None, channels=None, use_std: bool = False):
         """modules/measurand.py:716-761 is a NumPy-only plotting helper of the reference (scipy.stats.gaussian_kde on host arrays)
@@ -395,33 +387,24 @@ class HipMeasurand(AbstractMeasurand):
         """modules/measurand.py:620-655."""
         cls = x.__class__
         xv, yv = x._f64(), y._f64()
-        if xv.is_cuda and xv.shape == yv.shape and (x.std is None or x.std.shape == xv.shape) and (y.std is None or y.std.shape == yv.shape):
-            ad, ads, rd, rds = _engine().compute_difference(xv, x.std, yv, y.std, multiplier)   # hm_compute_difference
-            return cls(ad, ads), cls(rd, rds)
-        scale = multiplier * yv
-        abs_diff = xv - scale
-        rel_diff = abs_diff / scale
-        if x.std is None and y.std is None:
-            return cls(abs_diff, None), cls(rel_diff, None)
-        xs = 0 if x.std is None else x.std
-        ys = 0 if y.std is None else y.std
-        abs_std = torch.sqrt(xs ** 2 + (multiplier * ys) ** 2)
-        rel_std = torch.sqrt((xs / (multiplier * yv)) ** 2 + ((ys * xv) / (multiplier * yv ** 2)) ** 2)
-        return cls(abs_diff, abs_std), cls(rel_diff, rel_std)
+        if not xv.is_cuda:
+            raise RuntimeError("compute_difference needs the images on the device (there is no CPU fallback)")
+        if xv.shape != yv.shape:
+            raise NotImplementedError("hm_compute_difference takes two images of the same shape (the reference's only use, "
+                                      "ImageSet.compute_difference of two frames of one series)")
+        ad, ads, rd, rds = _engine().compute_difference(xv, x.std, yv, y.std, multiplier)   # hm_compute_difference
+        return cls(ad, ads), cls(rd, rds)
 
     @staticmethod
     def interpolate(x0: "HipMeasurand", x1: "HipMeasurand", y0: float, y1: float, y: float):
         """modules/measurand.py:657-681 (std formula as written)."""
         cls = x0.__class__
-        if x0._f64().is_cuda and x0.shape == x1.shape:
-            res, res_std = _engine().interpolate(x0._f64(), x0.std, x1._f64(), x1.std, y0, y1, y)   # hm_interpolate
-            return cls(res, res_std)
-        res = (x0._f64() * (y1 - y) + x1._f64() * (y - y0)) / (y1 - y0)
-        if x0.std is None and x1.std is None:
-            return cls(res, None)
-        a = 0 if x0.std is None else x0.std
-        b = 0 if x1.std is None else x1.std
-        return cls(res, torch.sqrt(a * ((y1 - y) / (y1 - y0)) ** 2 + b * ((y - y0) / (y1 - y0)) ** 2))
+        if not x0._f64().is_cuda:
+            raise RuntimeError("interpolate needs the images on the device (there is no CPU fallback)")
+        if x0.shape != x1.shape:
+            raise NotImplementedError("hm_interpolate takes two images of the same shape")
+        res, res_std = _engine().interpolate(x0._f64(), x0.std, x1._f64(), x1.std, y0, y1, y)   # hm_interpolate
+        return cls(res, res_std)
 
 
 def _keep(values: torch.Tensor, axis):

@@ -38,19 +38,42 @@ def stacks_for_rank(n_stacks: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_stacks, world_size))
 
 
+def tiles_for_rank(n_tiles: int, rank: int, world_size: int) -> List[int]:
+    """Row tiles of ONE image dealt to the ranks (config 4: 8 tiles; rank r takes tiles r, r + G, ...)."""
+    return list(range(rank, n_tiles, world_size))
+
+
+def _pinned_like(a: np.ndarray) -> torch.Tensor:
+    t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype)
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
 def merge_row_tile(frames_host: Sequence[np.ndarray], exposures, icrf, icrf_diff=None, stds_host=None,
                    darks_host=None, dark_min=None, median_k: int = 3, flat_host=None, flat_std_host=None,
-                   ff_mean=None, ff_std_mean=None, rank: int = 0, world_size: int = 1, device=None):
-    """Merge this rank's row tile of a stack that lives in host memory. Uploads only the rows the tile
-    needs (tile + halo), launches the fused kernel, returns (row0, row1, val, std) with host arrays."""
+                   ff_mean=None, ff_std_mean=None, rank: int = 0, world_size: int = 1, device=None,
+                   tile: Optional[Tuple[int, int]] = None):
+    """Merge this rank's row tile of a stack that lives in host memory. Only the rows the tile needs (tile + halo) travel:
+    they are staged in pinned buffers and copied with asynchronous H2D copies on the current stream, the fused kernel is
+    launched behind them, and the result comes back through pinned buffers with asynchronous D2H copies (one
+    synchronisation at the end). Returns (row0, row1, val, std) with host arrays. `tile` overrides the (row0, row1) that
+    row_tile_bounds() gives this rank (a rank that owns several tiles calls once per tile)."""
     from . import engine
     H = frames_host[0].shape[0]
-    r0, r1 = row_tile_bounds(H, world_size)[rank]
+    r0, r1 = row_tile_bounds(H, world_size)[rank] if tile is None else tile
     use_hot = darks_host is not None and any(d is not None for d in darks_host)
     b0, b1 = halo_bounds(r0, r1, H, median_k if use_hot else 0)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    up = lambda a, lo, hi: torch.as_tensor(np.ascontiguousarray(a[lo:hi]), device=device)   # noqa: E731
+    if r1 == r0:
+        empty = np.empty((0,) + tuple(frames_host[0].shape[1:]))
+        return r0, r1, empty, (None if stds_host is None else empty.copy())
+    staged = []
+
+    def up(a, lo, hi):
+        h = _pinned_like(a[lo:hi])
+        h.numpy()[...] = a[lo:hi]                        # pageable -> pinned (the only host copy), then DMA
+        staged.append(h)
+        return h.to(device, non_blocking=True)
     frames = [up(f, b0, b1) for f in frames_host]
     stds = None if stds_host is None else [up(s, b0, b1) for s in stds_host]
     darks = None if not use_hot else [None if d is None else up(d, b0, b1) for d in darks_host]
@@ -59,27 +82,152 @@ def merge_row_tile(frames_host: Sequence[np.ndarray], exposures, icrf, icrf_diff
         kw.update(flat=up(flat_host, r0, r1), ff_mean=ff_mean)
         if stds is not None:
             kw.update(flat_std=up(flat_std_host, r0, r1), ff_std_mean=ff_std_mean)
-    if r1 == r0:
-        empty = np.empty((0,) + tuple(frames_host[0].shape[1:]))
-        return r0, r1, empty, (None if stds is None else empty.copy())
     out = engine.merge(frames, exposures, icrf, icrf_diff, stds, darks=darks, dark_min=dark_min, median_k=median_k,
                        height=H, row0=r0, rows=r1 - r0, buf_row0=b0, **kw)
-    val = out["val"].cpu().numpy()
-    std = out["std"].cpu().numpy() if "std" in out else None
-    return r0, r1, val, std
+    h_val = torch.empty(out["val"].shape, dtype=torch.float64).pin_memory()
+    h_val.copy_(out["val"], non_blocking=True)
+    h_std = None
+    if "std" in out:
+        h_std = torch.empty(out["std"].shape, dtype=torch.float64).pin_memory()
+        h_std.copy_(out["std"], non_blocking=True)
+    torch.cuda.current_stream(device).synchronize()
+    return r0, r1, h_val.numpy(), (None if h_std is None else h_std.numpy())
+
+
+class RowTileSet:
+    """The row tiles of ONE large image that this rank owns, resident on its GPU (config 4: a 15 x 8192 x 8192 x 3
+    stack cut into 8 tiles of 1024 rows). `launch()` enqueues one fused merge per tile; `download()` brings the results
+    back through pinned buffers with asynchronous D2H copies on a side stream (tile k's copy overlaps tile k+1's);
+    `assemble()` concatenates the tiles of all ranks on `dst` through the CPU (gloo) group with tensor gathers into a
+    preallocated image - no pickling, no per-tile temporaries. There is no GPU<->GPU traffic on this path."""
+
+    def __init__(self, height: int, n_tiles: int, rank: int = 0, world_size: int = 1, median_k: int = 0):
+        self.height, self.n_tiles, self.rank, self.world = height, n_tiles, rank, world_size
+        self.bounds = row_tile_bounds(height, n_tiles)
+        self.mine = tiles_for_rank(n_tiles, rank, world_size)
+        self.median_k = median_k
+        self.plans = {}
+        self._host = {}
+        self._copy_stream = None
+
+    def input_rows(self, tile: int) -> Tuple[int, int]:
+        r0, r1 = self.bounds[tile]
+        return halo_bounds(r0, r1, self.height, self.median_k)
+
+    def add_tile(self, tile: int, frames, exposures, icrf, icrf_diff=None, stds=None, **kw):
+        """frames / stds / darks: device tensors covering input_rows(tile); flat / flat_std cover the tile's own rows."""
+        from . import engine
+        r0, r1 = self.bounds[tile]
+        b0, _ = self.input_rows(tile)
+        self.plans[tile] = engine.plan_merge(frames, exposures, icrf, icrf_diff, stds, height=self.height, row0=r0, rows=r1 - r0,
+                                             buf_row0=b0, **kw)
+
+    def launch(self, stream: Optional[int] = None) -> None:
+        for t in self.mine:
+            self.plans[t].launch(stream)
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return sum(self.plans[t].algorithmic_bytes for t in self.mine)
+
+    def download(self):
+        """{tile: (val, std | None)} as pinned host tensors; the merges must have been launched on the current stream."""
+        dev = self.plans[self.mine[0]].device
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._copy_stream.wait_event(ev)
+        with torch.cuda.stream(self._copy_stream):
+            for t in self.mine:
+                o = self.plans[t].outputs
+                if t not in self._host:
+                    self._host[t] = (torch.empty(o["val"].shape, dtype=torch.float64).pin_memory(),
+                                     torch.empty(o["std"].shape, dtype=torch.float64).pin_memory() if "std" in o else None)
+                hv, hs = self._host[t]
+                hv.copy_(o["val"], non_blocking=True)
+                if hs is not None:
+                    hs.copy_(o["std"], non_blocking=True)
+        self._copy_stream.synchronize()
+        return {t: self._host[t] for t in self.mine}
+
+    def assemble(self, group=None, dst: int = 0):
+        """(val, std) of the whole image as host tensors on `dst`, (None, None) elsewhere."""
+        local = self.download()
+        return gather_tiles(local, self.bounds, group=group, dst=dst, world_size=self.world, rank=self.rank)
+
+
+def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst: int = 0, world_size: int = 1, rank: int = 0):
+    """Assemble {tile index: (val, std | None)} dictionaries of all ranks into one image on `dst`. With one rank this is a
+    concatenation into a preallocated buffer; with several, every tile travels as ONE tensor send / receive over the CPU
+    (gloo) group straight into its rows of the destination image."""
+    some = next(iter(local.values())) if local else None
+    with_std = some is not None and some[1] is not None
+    if world_size == 1:
+        shape_tail = tuple(some[0].shape[1:])
+        H = bounds[-1][1]
+        val = torch.empty((H,) + shape_tail, dtype=torch.float64)
+        std = torch.empty((H,) + shape_tail, dtype=torch.float64) if with_std else None
+        for t, (v, s) in local.items():
+            r0, r1 = bounds[t]
+            val[r0:r1] = torch.as_tensor(v)
+            if with_std:
+                std[r0:r1] = torch.as_tensor(s)
+        return val, std
+    import torch.distributed as dist
+    n_tiles = len(bounds)
+    meta = torch.zeros(4, dtype=torch.int64)                      # (W, C, with_std, have_any) agreed through a max-reduce
+    if some is not None:
+        meta[0], meta[1], meta[2], meta[3] = some[0].shape[1], some[0].shape[2], int(with_std), 1
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+    W, Cc, with_std = int(meta[0]), int(meta[1]), bool(meta[2])
+    val = std = None
+    if rank == dst:
+        H = bounds[-1][1]
+        val = torch.empty((H, W, Cc), dtype=torch.float64)
+        std = torch.empty((H, W, Cc), dtype=torch.float64) if with_std else None
+    reqs = []
+    for t in range(n_tiles):
+        owner = t % world_size
+        r0, r1 = bounds[t]
+        if r1 == r0:
+            continue
+        if owner == dst:
+            if rank == dst:
+                val[r0:r1] = torch.as_tensor(local[t][0])
+                if with_std:
+                    std[r0:r1] = torch.as_tensor(local[t][1])
+            continue
+        if rank == owner:
+            reqs.append(dist.isend(torch.as_tensor(local[t][0]).contiguous(), dst=dst, group=group, tag=2 * t))
+            if with_std:
+                reqs.append(dist.isend(torch.as_tensor(local[t][1]).contiguous(), dst=dst, group=group, tag=2 * t + 1))
+        elif rank == dst:
+            reqs.append(dist.irecv(val[r0:r1], src=owner, group=group, tag=2 * t))     # rows of a C-contiguous image: contiguous
+            if with_std:
+                reqs.append(dist.irecv(std[r0:r1], src=owner, group=group, tag=2 * t + 1))
+    for r in reqs:
+        r.wait()
+    return val, std
 
 
 def gather_row_tiles(local_val: np.ndarray, local_std: Optional[np.ndarray], group=None, dst: int = 0):
-    """Host-side assembly of the tiles on rank `dst` through the CPU process group (gloo): tiles are
-    concatenated in rank order. Returns (val, std) on dst, (None, None) elsewhere."""
+    """Host-side assembly of ONE tile per rank (rank r owns tile r) on rank `dst` through the CPU process group (gloo):
+    every tile is received straight into its rows of a preallocated image (tensor send / receive - no pickling).
+    Returns (val, std) NumPy arrays on dst, (None, None) elsewhere."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    payload = (local_val, local_std)
-    gathered = [None] * world if rank == dst else None
-    dist.gather_object(payload, gathered, dst=dst, group=group)
+    rows = torch.zeros(world, dtype=torch.int64)
+    rows[rank] = local_val.shape[0]
+    dist.all_reduce(rows, group=group)
+    edges = [0]
+    for r in range(world):
+        edges.append(edges[-1] + int(rows[r]))
+    bounds = [(edges[r], edges[r + 1]) for r in range(world)]
+    local = {rank: (torch.as_tensor(np.ascontiguousarray(local_val)),
+                    None if local_std is None else torch.as_tensor(np.ascontiguousarray(local_std)))}
+    val, std = gather_tiles(local, bounds, group=group, dst=dst, world_size=world, rank=rank)
     if rank != dst:
         return None, None
-    val = np.concatenate([g[0] for g in gathered], axis=0)
-    std = None if gathered[0][1] is None else np.concatenate([g[1] for g in gathered], axis=0)
-    return val, std
+    return val.numpy(), (None if std is None else std.numpy())

@@ -18,6 +18,11 @@ MEDIAN_FILTER_KERNEL_SIZE = 3  # :65
 LOWER_LIN_LIM = 5              # :68
 UPPER_LIN_LIM = 250            # :69
 
+# Paths behind the reference's default arguments (global_settings.py:40-60). None = not configured: nothing is looked up.
+ICRF_CALIBRATED_FILE = None    # text table (BITS, C) read by process_HDR_image(ICRF=None), exposure_series.py:406-407
+DEFAULT_DARK_PATH = None       # directory of dark frames, exposure_series.py:409 / image_set.py:170
+DEFAULT_FLAT_PATH = None       # directory of flat fields, image_set.py:146-155
+
 
 def configure(**kw):
     """Override settings, e.g. configure(DARK_THRESHOLD=0.012, MEDIAN_FILTER_KERNEL_SIZE=5)."""

@@ -150,6 +150,9 @@ int hm_merge(const hm_merge_args* args /*[host]*/, void* stream);
 /* Algorithmic HBM bytes one hm_merge call moves: every input byte once, every output
  * byte once, LUTs excluded. Used by bench.py for roofline.achieved. */
 int64_t hm_merge_algorithmic_bytes(const hm_merge_args* args /*[host]*/);
+/* The kernels hm_merge() would launch for these arguments, in launch order, as text ("merge_u8_val3<N=7,...> +
+ * merge_fixup_hot<...>"): the same dispatch code runs with launching switched off. Same status codes as hm_merge. */
+int hm_merge_describe(const hm_merge_args* args, char* buf, int buf_len);
 
 /* ------------------------------------------------------------------------------------------
  * Row 8 standalone - AbstractMeasurand.filter_larger_than_by_map (modules/measurand.py:543-557):
@@ -198,6 +201,21 @@ int hm_binary_op(int op, const double* x1, const double* s1, const double* x2, c
 int hm_unary_op(int op, const double* x, const double* s, double* out_val, double* out_std,
                 int64_t n, void* stream);
 
+/* Measurand.__pow__ with a plain scalar exponent (modules/measurand.py:217-241; `S ** 2`, `** (1/2)` of the merge loop,
+ * modules/exposure_series.py:343,394): out = x ** exponent, out_std = |exponent * x ** (exponent - 1)| * s (the exponent
+ * has no uncertainty; its term of :237-238 is evaluated only where it is not +0). Exponents 2, 0.5, 1 and integers in
+ * [-8, 8] avoid pow(). s / out_std are NULL together. */
+int hm_pow_scalar(const double* x, const double* s /*nullable*/, double exponent, double* out_val, double* out_std /*nullable*/,
+                  int64_t n, void* stream);
+
+/* Measurand.extract (modules/measurand.py:352-373, `lib.take(val, dims, axis)`): out[o, k, i] = in[o, indices[k], i]
+ * for the dense (outer, axis_len, inner) view of the array; axis=None in the reference is outer = inner = 1 on the
+ * flattened array. std (nullable, with out_std) is taken with the same indices. Negative indices count from the end;
+ * an index out of range returns HM_ESHAPE (np.take raises IndexError). At most HM_TAKE_MAX indices per call. */
+#define HM_TAKE_MAX 16
+int hm_take_axis(const double* x, const double* s, double* out_val, double* out_std, int64_t outer, int64_t axis_len,
+                 int64_t inner, const int64_t* indices /*[host]*/, int n_indices, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * SURVEY.md 8(f)-1 - linearity statistics (ExposureSeries.process_linearity, modules/exposure_series.py:421-446)
  *   hm_apply_thresholds     apply_thresholds (modules/measurand.py:375-428), in place: elements with
@@ -209,6 +227,7 @@ int hm_unary_op(int op, const double* x, const double* s, double* out_val, doubl
  *                           weighted by 1/std when std is given, plus error = nanmean(std). out is 3*C
  *                           float64 on the device: [mean | std | error]; error is NaN without std.
  * ------------------------------------------------------------------------------------------ */
+#define HM_THRESHOLD_MAX_CHANNELS 32   /* hm_apply_thresholds: channels on the last axis (a slower one-element-per-thread kernel above HM_MAX_CHANNELS) */
 int hm_apply_thresholds(double* val, double* std /*nullable*/, const double* lower /*[host] C*/,
                         const double* upper /*[host] C*/, int64_t n, int C, void* stream);
 int hm_compute_difference(const double* x, const double* sx, const double* y, const double* sy, double multiplier,

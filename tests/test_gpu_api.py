@@ -307,3 +307,84 @@ def test_out_of_scope_methods_fail_loudly(M):
         m.compute_kernel_density_estimate(10)
     with pytest.raises(NotImplementedError):
         M(np.zeros((2, 2, 5))).compute_channel_histogram(8)
+
+
+# ------------------------------------------------------------------------------------------------ which path ran
+def test_measurand_methods_run_their_hip_kernels(M):
+    """Every Measurand method of the statistics / selection group is ONE libhdrmerge kernel (no torch arithmetic behind it):
+    the per-symbol call counter of the loaded library must move for exactly the symbol the method documents; shapes the
+    kernels do not take raise instead of silently running somewhere else."""
+    from camera_linearity_amd import _native as nat
+    rng = np.random.default_rng(5)
+    a, b = rng.random((6, 7, 3)) + 0.1, rng.random((6, 7, 3)) + 0.1
+    A, B = M(a, 0.1 * a), M(b, 0.1 * b)
+
+    def ran(symbol, fn):
+        before = dict(nat.lib.calls)
+        out = fn()
+        moved = {k for k, v in nat.lib.calls.items() if v != before.get(k, 0)}
+        assert symbol in moved, (symbol, moved)
+        return out
+    ex = ran("hm_take_axis", lambda: A.extract([2, 0], axis=-1))
+    np.testing.assert_array_equal(ex.val.cpu().numpy(), np.take(a, [2, 0], axis=-1))
+    np.testing.assert_array_equal(ex.std.cpu().numpy(), np.take(0.1 * a, [2, 0], axis=-1))
+    ex = ran("hm_take_axis", lambda: A.extract([5, 0, 17, -1]))                       # axis=None: the flattened array (np.take)
+    np.testing.assert_array_equal(ex.val.cpu().numpy(), np.take(a, [5, 0, 17, -1]))
+    ex = ran("hm_take_axis", lambda: A.extract(1, axis=0))
+    np.testing.assert_array_equal(ex.val.cpu().numpy(), np.take(a, [1], axis=0))
+    with pytest.raises(IndexError):
+        A.extract([3], axis=-1)
+    ran("hm_apply_thresholds", lambda: M(a.copy()).apply_thresholds([0.3, None, 0.2], [0.9, 0.8, None]))
+    wide = rng.random((5, 9))                                                         # 9 channels: the wide kernel, still HIP
+    W9 = M(wide.copy(), 0.1 * wide)
+    ran("hm_apply_thresholds", lambda: W9.apply_thresholds([0.2] * 9, [0.7] * 9))
+    want = wide.copy()
+    want[(want < 0.2) | (want > 0.7)] = np.nan
+    np.testing.assert_array_equal(W9.val.cpu().numpy(), want)
+    assert np.array_equal(np.isnan(W9.std.cpu().numpy()), np.isnan(want))
+    st_ = ran("hm_channel_statistics", lambda: A.compute_dimension_statistics(axis=(0, 1)))
+    assert tuple(st_["mean"].shape) == (3,)
+    st_all = ran("hm_channel_statistics", lambda: A.compute_dimension_statistics())  # axis=None: every element, 1/std weights
+    ref_all = orc.dimension_statistics(a, 0.1 * a, None)
+    for key in ("mean", "std", "error"):
+        np.testing.assert_allclose(float(st_all[key]), float(ref_all[key]), rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        A.compute_dimension_statistics(axis=1)
+    ran("hm_compute_difference", lambda: A.compute_difference(A, B, 0.5))
+    ran("hm_interpolate", lambda: A.interpolate(A, B, 1.0, 3.0, 1.5))
+    with pytest.raises(NotImplementedError):
+        A.compute_difference(A, M(b[:, :, :1]), 0.5)
+    with pytest.raises(NotImplementedError):
+        A.interpolate(A, M(b[:1]), 1.0, 3.0, 1.5)
+    ran("hm_binary_op", lambda: A ** 2)
+    from camera_linearity_amd import engine
+    ran("hm_merge", lambda: engine.merge([torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")] * 2, [1e-3, 2e-3], orc.synthetic_icrf()[0]))
+
+
+@pytest.mark.parametrize("p", [2, 0.5, 1, 3, -1, -2, 8, 0, 2.5, -0.75, 9])
+def test_pow_scalar_exponent(M, p):
+    """Measurand ** plain scalar (hm_pow_scalar: no pow() for 2, 1/2, 1 and small integers) against the reference's formula
+    (modules/measurand.py:217-241 evaluated by the oracle with NumPy's pow): value and propagated std to a few ulp; zeros and
+    negative values give NumPy's inf / NaN pattern."""
+    from camera_linearity_amd import _native as nat
+    rng = np.random.default_rng(17)
+    a = rng.random((9, 11, 3)) + 0.05
+    sa = 0.1 * a
+    before = nat.lib.calls["hm_pow_scalar"]
+    r = M(a, sa) ** p
+    assert nat.lib.calls["hm_pow_scalar"] == before + 1
+    rv, rs = orc.op_pow(a, sa, np.array([float(p)]), None)
+    close(r.val, rv, 1e-14)
+    np.testing.assert_allclose(r.std.cpu().numpy(), rs, rtol=1e-13)
+    assert (M(a) ** p).std is None
+    odd = np.array([0.0, -1.5, 2.0, np.inf, 0.25, 1.0, -0.0])                 # odd length: the scalar tail of the 2-per-lane kernel
+    with np.errstate(all="ignore"):
+        ov, os_ = orc.op_pow(odd, 0.1 * np.abs(odd) + 0.01, np.array([float(p)]), None)
+    got = M(odd, 0.1 * np.abs(odd) + 0.01) ** p
+    gv, gs = got.val.cpu().numpy(), got.std.cpu().numpy()
+    assert np.array_equal(np.isnan(gv), np.isnan(ov)) and np.array_equal(np.isinf(gv), np.isinf(ov))
+    fin = np.isfinite(ov)
+    np.testing.assert_allclose(gv[fin], ov[fin], rtol=1e-14)
+    assert np.array_equal(np.isnan(gs), np.isnan(os_)), (p, gs, os_)
+    fin = np.isfinite(os_)
+    np.testing.assert_allclose(gs[fin], os_[fin], rtol=1e-13)

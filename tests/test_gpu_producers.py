@@ -259,6 +259,88 @@ def test_from_dir_path_tiff_workflow(eng, tmp_path):
     assert np.array_equal(tiff_io.imread(tmp_path / "clip 10ms.std.tif"), ret["std"])
 
 
+def _write_series(tiff_io, folder, frames, stds, t, tag="bf 5x sample"):
+    folder.mkdir(parents=True, exist_ok=True)
+    for f, s, ti in zip(frames, stds, t):
+        name = f"{ti * 1000:g}ms {tag}.tif"
+        tiff_io.imwrite(folder / name, f)
+        if s is not None:
+            tiff_io.imwrite(folder / name.replace(".tif", " STD.tif"), s)
+
+
+def test_std_images_load_after_value_images(eng, tmp_path):
+    """The reference workflow order: series.load_value_images() first, then process_HDR_image. The merge loop of the
+    reference calls load_std_image() for every frame whatever is in memory (modules/exposure_series.py:376-377), so the
+    merged uncertainty must still be there - and a series where only some frames have a ' STD.tif' is an error, not a
+    silent value-only merge."""
+    from camera_linearity_amd import tiff_io
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    frames, stds, t = orc.synthetic_stack(12, 3, 24, 40, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    _write_series(tiff_io, tmp_path / "a", frames, stds, t)
+    series = ExposureSeries.from_dir_path(tmp_path / "a")[0]
+    series.load_value_images()
+    assert all(s.measurand.std is None for s in series.input_image_sets)
+    series.process_HDR_image(icrf, diff)
+    val, std = series.merged_image_set.to_numpy()
+    ref = orc.merge(frames, t, icrf, diff, stds=stds)
+    assert std is not None
+    np.testing.assert_allclose(val, ref["val"], rtol=1e-12)
+    np.testing.assert_allclose(std, ref["std"], rtol=1e-9)
+    _write_series(tiff_io, tmp_path / "b", frames, [stds[0], None, stds[2]], t)
+    partial = ExposureSeries.from_dir_path(tmp_path / "b")[0]
+    with pytest.raises(ValueError):
+        partial.process_HDR_image(icrf, diff)
+    partial.process_HDR_image(icrf, diff, use_std=False)
+    np.testing.assert_allclose(partial.merged_image_set.to_numpy()[0], ref["val"], rtol=1e-12)
+
+
+def test_process_hdr_image_default_arguments(eng, tmp_path):
+    """process_HDR_image() with no arguments, as a caller of the reference writes it (modules/exposure_series.py:399-409):
+    ICRF from settings.ICRF_CALIBRATED_FILE, dark frames from settings.DEFAULT_DARK_PATH, flat fields from
+    settings.DEFAULT_FLAT_PATH; equal to the explicit-argument call and to the oracle. Without a configured ICRF file it raises."""
+    from camera_linearity_amd import settings, tiff_io
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    n, h, w = 3, 32, 48
+    rng = np.random.default_rng(31)
+    t = np.array([0.02, 0.1, 0.4])                                        # two frames at or above DARK_THRESHOLD = 0.05 s
+    rad = rng.random((h, w, 3)) * 4
+    frames = [np.clip(np.around(rad * ti * 255 / (4 * t[1])), 0, 255).astype(np.uint8) for ti in t]
+    stds = [0.004 * (1 + rng.random((h, w, 3))) for _ in t]
+    icrf, diff = orc.synthetic_icrf()
+    dark = rng.integers(0, 4, size=(h, w, 3)).astype(np.uint8)
+    dark[rng.random((h, w, 3)) < 0.02] = 200
+    flat = np.clip(np.around(255 * (0.8 + 0.05 * rng.random((h, w, 3)))), 0, 255).astype(np.uint8)
+    flat_std = np.full((h, w, 3), 0.002)
+    _write_series(tiff_io, tmp_path / "series", frames, stds, t)
+    _write_series(tiff_io, tmp_path / "darks", [dark, dark, dark], [None] * 3, [0.05, 0.1, 0.4], tag="bf 5x dark")
+    _write_series(tiff_io, tmp_path / "flats", [flat], [flat_std], [0.1], tag="bf 5x flat")
+    np.savetxt(tmp_path / "icrf.txt", icrf)
+    series = ExposureSeries.from_dir_path(tmp_path / "series")[0]
+    with pytest.raises(ValueError):
+        series.process_HDR_image()
+    saved = {k: getattr(settings, k) for k in ("ICRF_CALIBRATED_FILE", "DEFAULT_DARK_PATH", "DEFAULT_FLAT_PATH")}
+    try:
+        settings.configure(ICRF_CALIBRATED_FILE=tmp_path / "icrf.txt", DEFAULT_DARK_PATH=tmp_path / "darks", DEFAULT_FLAT_PATH=tmp_path / "flats")
+        series.process_HDR_image()
+        val, std = series.merged_image_set.to_numpy()
+    finally:
+        settings.configure(**saved)
+    explicit = ExposureSeries.from_dir_path(tmp_path / "series")[0]
+    explicit.process_HDR_image(np.loadtxt(tmp_path / "icrf.txt"), None, dark_list=ImageSet.multiple_from_path(tmp_path / "darks"),
+                               flat_list=ImageSet.multiple_from_path(tmp_path / "flats"))
+    ev, es = explicit.merged_image_set.to_numpy()
+    assert np.array_equal(val, ev) and np.array_equal(std, es)
+    fval = orc.unit_from_u8(flat)
+    dv = orc.unit_from_u8(dark)
+    ref = orc.merge(frames, t, np.loadtxt(tmp_path / "icrf.txt"), orc.icrf_derivative(np.loadtxt(tmp_path / "icrf.txt")), stds=stds,
+                    darks=[None, dv, dv], dark_threshold=settings.DARK_THRESHOLD, median_k=3, flat=fval, flat_std=flat_std,
+                    ff_mean=orc.flat_roi_mean(fval, h, w, 0.2), ff_std_mean=orc.flat_roi_mean(flat_std, h, w, 0.2))
+    np.testing.assert_allclose(val, ref["val_ff"], rtol=1e-12)
+    np.testing.assert_allclose(std, ref["std_ff"], rtol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------------ host-to-host pipeline
 @pytest.mark.parametrize("with_std,depth,count", [(False, 2, 5), (True, 3, 4), (False, 2, 1)])
 def test_merge_pipeline_matches_oracle(eng, with_std, depth, count):

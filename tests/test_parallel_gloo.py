@@ -72,3 +72,56 @@ def test_row_tiles_over_gloo(world):
         assert p.exitcode == 0
     assert np.array_equal(gval, whole["val"])
     assert np.array_equal(gstd, whole["std"])
+
+
+def _worker_tiles(rank, world, port, q, n_tiles):
+    """Several tiles per rank (config 4's shape: 8 tiles over G ranks), assembled with parallel.gather_tiles."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_linearity_amd import parallel
+    frames, stds, t, dark, icrf, diff = _stack()
+    H = frames[0].shape[0]
+    bounds = parallel.row_tile_bounds(H, n_tiles)
+    darkv = orc.unit_from_u8(dark)
+    local = {}
+    for tile in parallel.tiles_for_rank(n_tiles, rank, world):
+        r0, r1 = bounds[tile]
+        b0, b1 = parallel.halo_bounds(r0, r1, H, 3)
+        band = slice(b0, b1)
+        out = orc.merge([f[band] for f in frames], t, icrf, diff, stds=[s[band] for s in stds],
+                        darks=[None, darkv[band], darkv[band], darkv[band]], dark_threshold=0.075, median_k=3)
+        local[tile] = (torch.as_tensor(out["val"][r0 - b0:r1 - b0].copy()), torch.as_tensor(out["std"][r0 - b0:r1 - b0].copy()))
+    val, std = parallel.gather_tiles(local, bounds, dst=0, world_size=world, rank=rank)
+    if rank == 0:
+        q.put((val.numpy(), std.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_tiles", [(2, 5), (3, 8)])
+def test_many_row_tiles_per_rank_over_gloo(world, n_tiles):
+    frames, stds, t, dark, icrf, diff = _stack()
+    darkv = orc.unit_from_u8(dark)
+    whole = orc.merge(frames, t, icrf, diff, stds=stds, darks=[None, darkv, darkv, darkv], dark_threshold=0.075, median_k=3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tiles, args=(r, world, port, q, n_tiles)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gval, gstd = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(gval, whole["val"])
+    assert np.array_equal(gstd, whole["std"])
+
+
+def test_gather_tiles_single_rank():
+    from camera_linearity_amd import parallel
+    rng = np.random.default_rng(3)
+    img = rng.random((17, 5, 3))
+    bounds = parallel.row_tile_bounds(17, 4)
+    local = {t: (torch.as_tensor(img[r0:r1].copy()), None) for t, (r0, r1) in enumerate(bounds)}
+    val, std = parallel.gather_tiles(local, bounds)
+    assert std is None and np.array_equal(val.numpy(), img)

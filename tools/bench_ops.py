@@ -37,7 +37,11 @@ CASES = {
     "__add__ with std (measurand.py:106)": (lambda: engine.elementwise_binary(nat.HM_OP_ADD, v, sd, v2, sd), E * 48),
     "__mul__ with std": (lambda: engine.elementwise_binary(nat.HM_OP_MUL, v, sd, v2, sd), E * 48),
     "__truediv__ with std": (lambda: engine.elementwise_binary(nat.HM_OP_DIV, v, sd, v2, sd), E * 48),
-    "__pow__ scalar exponent, no std": (lambda: engine.elementwise_binary(nat.HM_OP_POW, v2, None, torch.tensor([2.0], device=dev, dtype=torch.float64), None), E * 16),
+    "__pow__ array exponent (generic pow), no std": (lambda: engine.elementwise_binary(nat.HM_OP_POW, v2, None, torch.tensor([2.0], device=dev, dtype=torch.float64), None), E * 16),
+    "__pow__ scalar 2, no std (S ** 2, exposure_series.py:343)": (lambda: engine.pow_scalar(v2, None, 2.0), E * 16),
+    "__pow__ scalar 1/2, no std (exposure_series.py:394)": (lambda: engine.pow_scalar(v2, None, 0.5), E * 16),
+    "__pow__ scalar 2 with std": (lambda: engine.pow_scalar(v2, sd, 2.0), E * 32),
+    "__pow__ scalar 2.2 with std (general exponent)": (lambda: engine.pow_scalar(v2, sd, 2.2), E * 32),
     "normalize_by_map (flat field, with std)": (lambda: engine.normalize_by_map(v, sd, flat, flat_std, m, s), E * 41),
     "hot_pixel_filter u8 (dark map, 3x3 median)": (lambda: engine.hot_pixel_filter(dn, dark, 0.05, 3), E * 3),
     "roi_mean u8 (flat ROI 20 %)": (lambda: engine.roi_mean(flat, x0, x1, y0, y1), (x1 - x0) * (y1 - y0) * 3),
