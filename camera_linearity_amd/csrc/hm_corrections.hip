@@ -29,55 +29,70 @@ __global__ __launch_bounds__(256) void k_hot_filter(const T* __restrict__ x, con
     const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
     const bool vec_x = aligned_dev(x, 16) && aligned_dev(out, 16);
-    for (int64_t cb = wave0 * 64; cb < n_chunks; cb += n_waves * 64) {          // wave-uniform trip count
-        const int64_t chunk = cb + lane;
-        const int64_t e0 = chunk * EL;
-        const int cnt = chunk < n_chunks ? static_cast<int>(n - e0 < EL ? n - e0 : EL) : 0;
-        T v[EL];
-        uint32_t hotbits = 0;
-        if (cnt == EL && vec_x) {
-            const cu32x4 r = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(x + e0));
-            __builtin_memcpy(v, &r, 16);
-        } else {
-            for (int j = 0; j < cnt; ++j) v[j] = x[e0 + j];
-        }
-        if (map_u8 && cnt == EL && EL == 16 && aligned_dev(map_u8 + e0, 16)) {
-            const cu32x4 mr = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(map_u8 + e0));
-            const uint32_t w4[4] = {mr.x, mr.y, mr.z, mr.w};
+    // UN batches of 64 chunks per iteration: the 16-byte loads of x and of the map for all of them are issued before the first
+    // ballot (one batch per iteration left a single pair of loads in flight per lane: 0.56 of the roofline, r01e_bench_ops.json)
+    constexpr int UN = 2;
+    const int64_t wstride = n_waves * 64;
+    for (int64_t cb0 = wave0 * 64; cb0 < n_chunks; cb0 += UN * wstride) {       // wave-uniform trip count
+        T v[UN][EL];
+        uint32_t hotbits[UN];
+        int cnts[UN];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                hotbits |= (static_cast<int>((w4[j >> 2] >> (8 * (j & 3))) & 255u) >= min_dn) ? (1u << j) : 0u;   // measurand.py:545
-        } else {
-            for (int j = 0; j < cnt; ++j) {
-                const bool hot = map_u8 ? (static_cast<int>(map_u8[e0 + j]) >= min_dn) : (map_f64[e0 + j] > thr);
-                hotbits |= hot ? (1u << j) : 0u;
+        for (int q = 0; q < UN; ++q) {
+            const int64_t chunk = cb0 + q * wstride + lane;
+            const int64_t e0 = chunk * EL;
+            const int cnt = chunk < n_chunks ? static_cast<int>(n - e0 < EL ? n - e0 : EL) : 0;
+            cnts[q] = cnt;
+            hotbits[q] = 0;
+            if (cnt == EL && vec_x) {
+                const cu32x4 r = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(x + e0));
+                __builtin_memcpy(v[q], &r, 16);
+            } else {
+                for (int j = 0; j < cnt; ++j) v[q][j] = x[e0 + j];
             }
-        }
-        unsigned long long pending = __ballot(hotbits != 0);
-        while (pending) {                                                        // rare
-            const int src = __ffsll(static_cast<long long>(pending)) - 1;
-            pending &= pending - 1;
-            uint32_t bits = __builtin_amdgcn_readlane(hotbits, src);
-            const int64_t base = (cb + src) * EL;
-            while (bits) {
-                const int j = __ffs(static_cast<int>(bits)) - 1;
-                bits &= bits - 1;
-                const int64_t e = base + j;
-                const int64_t wc = W * C;
-                const int64_t row = e / wc, rem = e % wc;
-                const T med = wave_median(x, H, W, C, 0, row, rem / C, static_cast<int>(rem % C), k);
-                if (lane == src) {
+            if (map_u8 && cnt == EL && EL == 16 && aligned_dev(map_u8 + e0, 16)) {
+                const cu32x4 mr = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(map_u8 + e0));
+                const uint32_t w4[4] = {mr.x, mr.y, mr.z, mr.w};
 #pragma unroll
-                    for (int q = 0; q < EL; ++q) v[q] = (q == j) ? med : v[q];
+                for (int j = 0; j < 16; ++j)
+                    hotbits[q] |= (static_cast<int>((w4[j >> 2] >> (8 * (j & 3))) & 255u) >= min_dn) ? (1u << j) : 0u;   // measurand.py:545
+            } else {
+                for (int j = 0; j < cnt; ++j) {
+                    const bool hot = map_u8 ? (static_cast<int>(map_u8[e0 + j]) >= min_dn) : (map_f64[e0 + j] > thr);
+                    hotbits[q] |= hot ? (1u << j) : 0u;
                 }
             }
         }
-        if (cnt == EL && vec_x) {
-            cu32x4 r;
-            __builtin_memcpy(&r, v, 16);
-            __builtin_nontemporal_store(r, reinterpret_cast<cu32x4*>(out + e0));
-        } else {
-            for (int j = 0; j < cnt; ++j) out[e0 + j] = v[j];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int64_t cb = cb0 + q * wstride;
+            unsigned long long pending = __ballot(hotbits[q] != 0);
+            while (pending) {                                                        // rare
+                const int src = __ffsll(static_cast<long long>(pending)) - 1;
+                pending &= pending - 1;
+                uint32_t bits = __builtin_amdgcn_readlane(hotbits[q], src);
+                const int64_t base = (cb + src) * EL;
+                while (bits) {
+                    const int j = __ffs(static_cast<int>(bits)) - 1;
+                    bits &= bits - 1;
+                    const int64_t e = base + j;
+                    const int64_t wc = W * C;
+                    const int64_t row = e / wc, rem = e % wc;
+                    const T med = wave_median(x, H, W, C, 0, row, rem / C, static_cast<int>(rem % C), k);
+                    if (lane == src) {
+#pragma unroll
+                        for (int p = 0; p < EL; ++p) v[q][p] = (p == j) ? med : v[q][p];
+                    }
+                }
+            }
+            const int64_t e0 = (cb + lane) * EL;
+            if (cnts[q] == EL && vec_x) {
+                cu32x4 r;
+                __builtin_memcpy(&r, v[q], 16);
+                __builtin_nontemporal_store(r, reinterpret_cast<cu32x4*>(out + e0));
+            } else {
+                for (int j = 0; j < cnts[q]; ++j) out[e0 + j] = v[q][j];
+            }
         }
     }
 }

@@ -149,6 +149,88 @@ __global__ __launch_bounds__(256) void k_linearize(const void* __restrict__ in, 
     }
 }
 
+
+// ---------------- linearize, streaming form ----------------
+// The shape of the merge kernels (hm_merge.hip, merge_u8_val3) for one frame: a wave owns groups of 3 x 128 = 384 consecutive
+// elements (128 whole pixels for C = 3, so the channel of element j of sub-unit s is a compile-time function of (s, j) on top of a
+// lane constant), lane l handles elements 2l, 2l + 1 of a sub-unit - one ushort (uint8 input) or one 16-byte (float64 input) load
+// per sub-unit and 16-byte stores that make every store instruction a contiguous 1 KB; the NEXT group's loads are issued before
+// the current group's gathers. The general kernel below issues one load per lane and loop iteration and waits for it: a wave then
+// spends its life in HBM round trips (0.55-0.60 of the roofline where the table-free hm_u8_to_unit_f64 gets 0.79 on the same
+// traffic). Takes C == 3 with a per-channel table, or any C with a single table (lut_stride == 1), on aligned buffers; hm_linearize_*
+// sends the body here and the tail (n mod 384) and everything else to k_linearize.
+constexpr uint32_t kLinSub = 128, kLinU = 3, kLinGroup = kLinSub * kLinU;
+
+template <bool F64IN, bool STD, bool PERCH>
+__global__ __launch_bounds__(256) void k_linearize_stream(const void* __restrict__ in, const double* __restrict__ sd,
+                                                          const double* __restrict__ icrf, const double* __restrict__ icrf_diff,
+                                                          double* __restrict__ out_val, double* __restrict__ out_std,
+                                                          uint8_t* __restrict__ out_idx, uint32_t n_groups) {
+    typedef typename LinEntry<STD>::type Entry;
+    constexpr int ENT = sizeof(Entry);
+    __shared__ __attribute__((aligned(16))) Entry t[256 * (PERCH ? 3 : 1)];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gstride = gridDim.x * 4u;
+    uint32_t g = blockIdx.x * 4u + wave;                                            // wave-uniform
+    const uint8_t* dn = static_cast<const uint8_t*>(in);
+    const double* vin = static_cast<const double*>(in);
+
+    uint32_t rA[kLinU], rB[kLinU];                                                  // uint8 input: two DNs per register
+    f64x2 xA[F64IN ? kLinU : 1], xB[F64IN ? kLinU : 1];                             // float64 input
+    f64x2 sA[STD ? kLinU : 1], sB[STD ? kLinU : 1];
+    auto load = [&](uint32_t grp, uint32_t (&r)[kLinU], f64x2 (&x)[F64IN ? kLinU : 1], f64x2 (&sv)[STD ? kLinU : 1]) {
+        const int64_t base = static_cast<int64_t>(grp) * kLinGroup;                 // scalar
+#pragma unroll
+        for (int s_ = 0; s_ < static_cast<int>(kLinU); ++s_) {
+            if constexpr (F64IN) x[s_] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(vin + base + kLinSub * s_) + lane);
+            else r[s_] = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(dn + base + kLinSub * s_) + lane);
+            if constexpr (STD) sv[s_] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sd + base + kLinSub * s_) + lane);
+        }
+    };
+    if (g < n_groups) load(g, rA, xA, sA);
+    for (int i = threadIdx.x; i < 256 * (PERCH ? 3 : 1); i += 256) t[i] = lin_entry<STD>(icrf[i], STD ? icrf_diff[i] : 0.0);
+    __syncthreads();
+    if (g >= n_groups) return;
+    const uint32_t k = PERCH ? (lane * 2u) % 3u : 0u;                               // channel of the lane's first element in sub-unit 0
+    const uint32_t off[3] = {k * ENT, ((k + 1u) % 3u) * ENT, ((k + 2u) % 3u) * ENT};
+
+    auto process = [&](uint32_t grp, const uint32_t (&r)[kLinU], const f64x2 (&x)[F64IN ? kLinU : 1], const f64x2 (&sv)[STD ? kLinU : 1]) {
+        const int64_t base = static_cast<int64_t>(grp) * kLinGroup;
+#pragma unroll
+        for (int s_ = 0; s_ < static_cast<int>(kLinU); ++s_) {
+            uint32_t k0, k1;
+            if constexpr (F64IN) {                                                   // around(val * MAX_DN).astype(uint8): half to even, wrap (measurand.py:503)
+                k0 = static_cast<uint32_t>(static_cast<int64_t>(rint(x[s_].x * 255.0))) & 255u;
+                k1 = static_cast<uint32_t>(static_cast<int64_t>(rint(x[s_].y * 255.0))) & 255u;
+            } else { k0 = r[s_] & 255u; k1 = r[s_] >> 8; }
+            const char* tb = reinterpret_cast<const char*>(t);
+            const uint32_t a0 = PERCH ? __umul24(k0, 3u * ENT) + off[(2 * s_) % 3] : k0 * ENT;
+            const uint32_t a1 = PERCH ? __umul24(k1, 3u * ENT) + off[(2 * s_ + 1) % 3] : k1 * ENT;
+            const Entry g0 = *reinterpret_cast<const Entry*>(tb + a0), g1 = *reinterpret_cast<const Entry*>(tb + a1);
+            f64x2 o; o.x = lin_g(g0); o.y = lin_g(g1);
+            __builtin_nontemporal_store(o, reinterpret_cast<f64x2*>(out_val + base + kLinSub * s_) + lane);
+            if constexpr (STD) {
+                f64x2 w; w.x = lin_d(g0) * sv[s_].x; w.y = lin_d(g1) * sv[s_].y;     // measurand.py:512
+                __builtin_nontemporal_store(w, reinterpret_cast<f64x2*>(out_std + base + kLinSub * s_) + lane);
+            }
+            if constexpr (F64IN) {
+                if (out_idx) reinterpret_cast<uint16_t*>(out_idx + base + kLinSub * s_)[lane] = static_cast<uint16_t>(k0 | (k1 << 8));
+            }
+        }
+    };
+    while (true) {                                                                   // A holds group g
+        if (g + gstride >= n_groups) { process(g, rA, xA, sA); break; }
+        load(g + gstride, rB, xB, sB);
+        process(g, rA, xA, sA);
+        g += gstride;                                                                // B holds group g
+        if (g + gstride >= n_groups) { process(g, rB, xB, sB); break; }
+        load(g + gstride, rA, xA, sA);
+        process(g, rB, xB, sB);
+        g += gstride;
+    }
+}
+
 }  // namespace hm
 
 using namespace hm;
@@ -186,9 +268,39 @@ static int linearize_common(bool f64in, const void* in, const double* sd, const 
     if (n == 0) return HM_OK;
     if (!aligned(out_val, 8) || (out_std && !aligned(out_std, 8)) || (sd && !aligned(sd, 8)) || (f64in && !aligned(in, 8)))
         return HM_EALIGN;
-    const unsigned grid = stream_grid(f64in ? n : (n + 1) / 2, 256, 8);
     const bool with_std = sd && icrf_diff && out_std;                       // measurand.py:498-500
-#define HM_LIN(F, S) hipLaunchKernelGGL((k_linearize<F, S>), dim3(grid), dim3(256), 0, as_stream(stream), in, sd, icrf, icrf_diff, \
+    hipStream_t st = as_stream(stream);
+    // streaming kernel for the body (whole groups of 384 elements) when the shape and the alignment allow it
+    int64_t body = 0;
+    const bool perch = lut_stride > 1;
+    const bool shape_ok = (perch && C == 3) || !perch;
+    const bool align_ok = aligned(out_val, 16) && (!with_std || (aligned(sd, 16) && aligned(out_std, 16))) &&
+                          (f64in ? aligned(in, 16) : aligned(in, 2)) && (!out_idx || aligned(out_idx, 2));
+    if (shape_ok && align_ok && n / kLinGroup > 0 && n / kLinGroup < (int64_t{1} << 31)) {
+        const uint32_t groups = static_cast<uint32_t>(n / kLinGroup);
+        body = static_cast<int64_t>(groups) * kLinGroup;
+        const unsigned sgrid = stream_grid(groups, 4, 8);
+#define HM_LINS(F, S, P) hipLaunchKernelGGL((k_linearize_stream<F, S, P>), dim3(sgrid), dim3(256), 0, st, in, sd, icrf, icrf_diff, out_val, out_std, out_idx, groups)
+        if (f64in) {
+            if (with_std) { if (perch) HM_LINS(true, true, true); else HM_LINS(true, true, false); }
+            else          { if (perch) HM_LINS(true, false, true); else HM_LINS(true, false, false); }
+        } else {
+            if (with_std) { if (perch) HM_LINS(false, true, true); else HM_LINS(false, true, false); }
+            else          { if (perch) HM_LINS(false, false, true); else HM_LINS(false, false, false); }
+        }
+#undef HM_LINS
+        if (body == n) return launch_status();
+        // tail: fewer than 384 elements, through the general kernel (body is a multiple of 3, so element % C is unchanged for C = 3;
+        // a single table does not look at the channel)
+        in = f64in ? static_cast<const void*>(static_cast<const double*>(in) + body) : static_cast<const void*>(static_cast<const uint8_t*>(in) + body);
+        if (sd) sd += body;
+        out_val += body;
+        if (out_std) out_std += body;
+        if (out_idx) out_idx += body;
+        n -= body;
+    }
+    const unsigned grid = stream_grid(f64in ? n : (n + 1) / 2, 256, 8);
+#define HM_LIN(F, S) hipLaunchKernelGGL((k_linearize<F, S>), dim3(grid), dim3(256), 0, st, in, sd, icrf, icrf_diff, \
                                         out_val, out_std, out_idx, n, C, lut_stride)
     if (f64in) { if (with_std) HM_LIN(true, true); else HM_LIN(true, false); }
     else       { if (with_std) HM_LIN(false, true); else HM_LIN(false, false); }

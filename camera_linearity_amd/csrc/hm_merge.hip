@@ -507,6 +507,15 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #ifndef HM_STD_FB
 #define HM_STD_FB 2      // std kernel, pass 2: frames per scheduling bundle
 #endif
+#ifndef HM_F64_KEEP_W
+#define HM_F64_KEEP_W 1      // float64-frame std kernel: keep pass 1's weights in registers for pass 2 (N <= 8): one exp() per
+#endif                       // element-frame instead of two; with 3 waves/SIMD 1 385 -> 1 296 us on 7 x 4096 x 4096 x 3 (profiles/r02c_ab_f64std.log)
+#ifndef HM_FLAT_PREFETCH
+#define HM_FLAT_PREFETCH 1   // flat-field operands fetched one group ahead, with the frame bytes
+#endif
+#ifndef HM_STD_EARLY
+#define HM_STD_EARLY 1       // std + flat-field kernel: issue every std load of a sub-unit before pass 1 (N <= HM_PIN_NF). A/B on one
+#endif                       // box (tools/ab3.sh, profiles/r02_ab_std1.log): config 3 890 -> 847 us; without the flat field it costs 10 %, so FLAT only
 #ifndef HM_PIN_NF
 #define HM_PIN_NF 8      // std kernel: above this N, pass 2 re-derives its per-frame addresses (registers)
 #endif
@@ -541,8 +550,25 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
             for (int s = 0; s < U; ++s) dst[i][s] = ld_u16(p + kSub * s + lane2);
         }
     };
+    // flat-field operands of a group (FLAT only): with HM_FLAT_PREFETCH they are fetched one group ahead, with the frame bytes
+    // (three waves per SIMD do not hide a load issued at the top of the sub-unit that consumes it)
+    uint32_t fl_dn[U];
+    f64x2 fl_v[U], fl_s[U];
+    auto load_flat = [&](uint32_t grp, uint32_t (&dn)[U], f64x2 (&v)[U], f64x2 (&sd)[U]) {
+        const int64_t fb = static_cast<int64_t>(grp) * GROUP;               // scalar, relative to row0
+#pragma unroll
+        for (int s = 0; s < U; ++s) {
+            if (a.flat_u8) dn[s] = ld_u16(a.flat_u8 + fb + kSub * s + lane2);
+            else v[s] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_f64 + fb + kSub * s) + lane16));
+            if (STD) sd[s] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_std + fb + kSub * s) + lane16));
+        }
+    };
+    constexpr bool FLAT_PF = FLAT && PREFETCH && HM_FLAT_PREFETCH;
     // the first group's HBM loads are in flight while the workgroup builds its LDS tables
-    if (PREFETCH && g < n_groups) load_group(g, raw);
+    if (PREFETCH && g < n_groups) {
+        load_group(g, raw);
+        if constexpr (FLAT_PF) load_flat(g, fl_dn, fl_v, fl_s);
+    }
 
     if constexpr (!STD) {
         fill_val_tables<TAB>(lds, a);
@@ -564,15 +590,25 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
 
     for (; g < n_groups; g += gstride) {
         uint32_t cur[NF][U];
+        uint32_t cfl_dn[U];
+        f64x2 cfl_v[U], cfl_s[U];
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int s = 0; s < U; ++s) cur[i][s] = raw[i][s];
-            if (g + gstride < n_groups) load_group(g + gstride, raw);
+            if constexpr (FLAT_PF) {
+#pragma unroll
+                for (int s = 0; s < U; ++s) { cfl_dn[s] = fl_dn[s]; cfl_v[s] = fl_v[s]; cfl_s[s] = fl_s[s]; }
+            }
+            if (g + gstride < n_groups) {
+                load_group(g + gstride, raw);
+                if constexpr (FLAT_PF) load_flat(g + gstride, fl_dn, fl_v, fl_s);
+            }
         } else {
             load_group(g, cur);
         }
+        if constexpr (FLAT && !FLAT_PF) load_flat(g, cfl_dn, cfl_v, cfl_s);
         const int64_t gbase = static_cast<int64_t>(g) * GROUP;            // relative to row0, scalar
 
 #pragma unroll
@@ -589,18 +625,15 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
             if constexpr (FLAT) {
                 {
                     if (a.flat_u8) {
-                        const uint32_t f = ld_u16(a.flat_u8 + sbase + lane2);
+                        const uint32_t f = cfl_dn[s];
                         const double2 f0 = t_flat[f & 255u], f1 = t_flat[f >> 8];
                         F[0] = f0.x; iF2[0] = f0.y; F[1] = f1.x; iF2[1] = f1.y;
                     } else {
-                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_f64 + sbase) + lane16));
+                        const f64x2 f = cfl_v[s];
                         F[0] = f.x; F[1] = f.y;
                         if (STD) { iF2[0] = 1.0 / (F[0] * F[0]); iF2[1] = 1.0 / (F[1] * F[1]); }
                     }
-                    if (STD) {
-                        const f64x2 f = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(a.flat_std + sbase) + lane16));
-                        sF[0] = f.x; sF[1] = f.y;
-                    }
+                    if (STD) { sF[0] = cfl_s[s].x; sF[1] = cfl_s[s].y; }
                 }
             }
 
@@ -641,6 +674,14 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
             } else {
                 const double2* t_wdw = reinterpret_cast<const double2*>(lds);
                 const char* t_gd = lds + 16 * 256;
+                // HM_STD_EARLY (flat-field instantiations): all NF float64 std loads of the sub-unit are issued here, ahead of pass 1's
+                // gathers (4 VGPRs per frame: stacks of up to HM_PIN_NF frames only), instead of HM_STD_FB frames at a time inside pass 2
+                constexpr bool EARLY = HM_STD_EARLY && FLAT && NF <= HM_PIN_NF;
+                f64x2 sd_early[EARLY ? NF : 1];
+                if constexpr (EARLY) {
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) sd_early[i] = ld_f64x2_global(a.sd[i] + a.in_off + sbase, lane16);
+                }
                 // pass 1: S = sum_i w_i
                 double S[2];
 #pragma unroll
@@ -667,9 +708,13 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
 #pragma unroll
                 for (int i = 0; i < NF; ++i) {
                     const double it = a.inv_t[i];
-                    const double* sp = a.sd[i] + a.in_off + sbase;                               // scalar base
-                    if (NF > HM_PIN_NF || !FLAT) asm volatile("" : "+s"(sp));     // keep base + 32-bit lane offset addressing (no per-frame VGPR address pairs)
-                    const f64x2 sdv = ld_f64x2_global(sp, lane16);
+                    f64x2 sdv;
+                    if constexpr (EARLY) sdv = sd_early[i];
+                    else {
+                        const double* sp = a.sd[i] + a.in_off + sbase;                           // scalar base
+                        if (NF > HM_PIN_NF || !FLAT) asm volatile("" : "+s"(sp));     // keep base + 32-bit lane offset addressing (no per-frame VGPR address pairs)
+                        sdv = ld_f64x2_global(sp, lane16);
+                    }
                     uint32_t packed = cur[i][s];
                     if (NF > HM_PIN_NF || !FLAT) HM_PIN(packed);                  // re-extract the DNs here instead of keeping pass 1's indices alive
 #pragma unroll
@@ -1222,6 +1267,9 @@ __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
                 // caches - 7 KB per wave-iteration, 20 waves per CU - and costs 56 B/element of extra traffic);
                 // the weight is re-evaluated, exp() is not what bounds this kernel
                 f64x2 v[kF64Keep];
+#if HM_F64_KEEP_W
+                double wk[kF64Keep][2];                          // pass 1's weights, reused by pass 2 (one exp() per element-frame instead of two)
+#endif
 #pragma unroll
                 for (int i = 0; i < kF64Keep; ++i)
                     if (i < N) v[i] = ld2(static_cast<const double*>(a.frame[i]) + ibase);
@@ -1231,6 +1279,9 @@ __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
                             const double w = gauss_weight((j == 0 ? v[i].x : v[i].y) - 0.5);
+#if HM_F64_KEEP_W
+                            wk[i][j] = w;
+#endif
                             if (i == 0) S[j] = w; else S[j] += w;
                         }
                         HM_PIN(S[0]); HM_PIN(S[1]);                 // one frame's exp() pair at a time: their temporaries,
@@ -1244,8 +1295,13 @@ __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
                     if (i < N) {
                         const f64x2 sdv = ld2(a.sd[i] + ibase);
                         const double it = a.inv_t[i];
+#if HM_F64_KEEP_W
+                        pass2(i, 0, v[i].x, wk[i][0], sdv.x, it);
+                        pass2(i, 1, v[i].y, wk[i][1], sdv.y, it);
+#else
                         pass2(i, 0, v[i].x, gauss_weight(v[i].x - 0.5), sdv.x, it);
                         pass2(i, 1, v[i].y, gauss_weight(v[i].y - 0.5), sdv.y, it);
+#endif
                         HM_PIN(acc[0]); HM_PIN(acc[1]); HM_PIN(var[0]); HM_PIN(var[1]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -1309,12 +1365,13 @@ __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
 
 // The two entry points differ in the occupancy the register allocator is asked for (A/B on one box, tools/ab3.sh):
 // val-only runs best when it may use up to 168 VGPRs (3 waves/SIMD: more loads in flight per wave, 665 -> 599 us on
-// 7 x 4096 x 4096 x 3), the std kernel at 4 waves/SIMD (127 VGPRs + 20 B scratch, 1 382 -> 1 343 us).
+// 7 x 4096 x 4096 x 3); the std kernel ran best at 4 waves/SIMD while it re-evaluated its weights in pass 2 (127 VGPRs + 20 B
+// scratch, 1 382 -> 1 343 us) and at 3 waves/SIMD now that it keeps them (HM_F64_KEEP_W; at 4 waves the kept weights spill: 1 566 us).
 #ifndef HM_F64_VAL_WAVES
 #define HM_F64_VAL_WAVES 3
 #endif
 #ifndef HM_F64_STD_WAVES
-#define HM_F64_STD_WAVES 4
+#define HM_F64_STD_WAVES 3
 #endif
 template <int C, bool FLAT, bool SUMW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HM_F64_VAL_WAVES, HM_F64_VAL_WAVES))) void merge_f64_val(const MergeK a) {
@@ -1406,13 +1463,17 @@ static int launch_one(const MergeK& k, hipStream_t st) {
 // the val-only, no-extras configuration runs merge_u8_val3 unless a variant asks for the older merge_u8_fast (A/B runs).
 // variant 7UPM (tuning builds, N == HM_TUNE_NF only) selects merge_u8_val3<NF, U, PF, MAP>; 0 = the production choice.
 struct Val3Cfg { int u, pf, map; };
-constexpr Val3Cfg kVal3Default = {2, 1, 0};     // A/B on one box (profiles/r02_ab_val3_matrix2.json): 125.5 us against 130.0 us for merge_u8_fast and 133-135 us for the in-place refill
+// Production choice per frame count (A/B on one box, tools/ab_val3.py): up to 8 frames <U=2, PF=1> - 64 VGPRs, 125.5 us on config 2
+// against 130.0 us for merge_u8_fast and 133-135 us for the in-place refill (profiles/r02_ab_val3_matrix2.json); above that the second
+// register set costs occupancy (N = 15: 137 VGPRs) and the in-place refill with U = 3 wins (82 VGPRs; config-4 tile 105.0 us against
+// 109.3 us for both <2, 1> and merge_u8_fast, profiles/r02_ab_val3_n15.json).
+constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{2, 1, 0} : Val3Cfg{3, 0, 0}; }
 static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
-    c = kVal3Default;
+    c = val3_default(n_frames);
     if (variant == 0) return true;
     if (variant < 7000 || variant >= 8000 || n_frames != HM_TUNE_NF) return false;
     c.u = (variant / 100) % 10; c.pf = (variant / 10) % 10; c.map = variant % 10;
-    return (c.u == 2 || c.u == 3) && c.pf <= 1 && c.map <= 1;
+    return c.u >= 1 && c.u <= 3 && c.pf <= 1 && c.map <= 1;
 }
 static bool use_val3(int variant, int n_frames, bool with_std, bool extras) {
     Val3Cfg c;
@@ -1443,10 +1504,12 @@ static int launch_val3(const MergeK& k, hipStream_t st) {
             case 200: return launch_val3_cfg<NF, 2, 0, 0>(k, st);
             case 201: return launch_val3_cfg<NF, 2, 0, 1>(k, st);
             case 210: return launch_val3_cfg<NF, 2, 1, 0>(k, st);
-            default:  return launch_val3_cfg<NF, 2, 1, 1>(k, st);
+            case 211: return launch_val3_cfg<NF, 2, 1, 1>(k, st);
+            case 100: return launch_val3_cfg<NF, 1, 0, 0>(k, st);
+            default:  return launch_val3_cfg<NF, 1, 1, 0>(k, st);
         }
     } else {
-        return launch_val3_cfg<NF, kVal3Default.u, kVal3Default.pf, kVal3Default.map>(k, st);
+        return launch_val3_cfg<NF, val3_default(NF).u, val3_default(NF).pf, val3_default(NF).map>(k, st);
     }
 }
 

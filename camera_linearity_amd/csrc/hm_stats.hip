@@ -3,8 +3,8 @@
 //   hm_compute_difference    AbstractMeasurand.compute_difference        modules/measurand.py:620-655
 //   hm_interpolate           AbstractMeasurand.interpolate               modules/measurand.py:657-681
 //   hm_channel_statistics    compute_dimension_statistics(axis = all but the last)   modules/measurand.py:318-350
-// Streaming, HBM-bound; the statistics are two deterministic reduction passes (per-workgroup partials by wave
-// shuffles + LDS, then one workgroup), NaNs ignored exactly as np.nansum / np.nanmean / np.nanstd do.
+// Streaming, HBM-bound; the statistics are ONE deterministic reduction pass (per-thread Welford states combined with Chan's
+// formula by wave shuffles + LDS, then one workgroup), NaNs ignored exactly as np.nansum / np.nanmean / np.nanstd do.
 #include "hm_common.h"
 #include <algorithm>
 
@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void k_interpolate(const double* __restrict__ 
 }
 
 // ---- statistics -------------------------------------------------------------------------------
+// compute_dimension_statistics (modules/measurand.py:318-350) in ONE pass over the data. The reference's two NumPy passes
+// (mean, then sum of squared deviations from it) would read every byte twice; here every thread keeps a running (W, mean, M2)
+// of its elements (short blocks of shifted sums folded in with Chan's formula, see MomAcc) and thread, wave, workgroup and grid
+// partials are combined with the same pairwise formula in a fixed tree order (bit-reproducible; as stable as the two-pass form:
+// moments are always taken about a mean of the data they cover). NaNs are skipped exactly as np.nansum / np.nanmean do, term by
+// term: `Wall` sums every non-NaN weight (the reference's denominators), the moments take the elements whose v * w is not NaN.
 constexpr int kStatBlocks = 2040;                           // a multiple of 12: total threads divisible by C = 1..4
 
 static int stat_grid(int64_t n) {
@@ -91,44 +97,163 @@ static int stat_grid(int64_t n) {
     g = ((g + 11) / 12) * 12;
     return static_cast<int>(g < kStatBlocks ? g : kStatBlocks);
 }
-constexpr int kStatVals = 4;                                // per channel: 4 partial sums
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+struct Mom {
+    double Wall;        // sum of the non-NaN weights (unweighted: count of non-NaN values)
+    double W;           // weight of the elements in (mean, M2)
+    double mean, M2;    // weighted mean and sum of w (v - mean)^2 of those elements
+    double ss, cs;      // sum and count of the non-NaN stds (`error` = nanmean(std)); unused without std
+};
+constexpr int kMomVals = 6;
+__device__ __forceinline__ Mom mom_zero() { return Mom{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
+
+// Per-thread accumulation: blocks of kMomBlock elements are summed as shifted moments about K = the state's current mean
+// (S0 = sum w, S1 = sum w (v - K), S2 = sum w (v - K)^2: three FMAs per element, no division) and then folded into the running
+// (W, mean, M2) with Chan's formula - two divisions per block instead of two per element (the all-pairs kernel is FP64-VALU
+// bound). K tracks the data (the first block is centred on its first element), so S2 - S1^2 / S0 differences nothing large.
+constexpr int kMomBlock = 8;
+struct MomAcc {
+    Mom m;
+    double K, S0, S1, S2;
+    int nb;
+};
+__device__ __forceinline__ MomAcc acc_zero() { return MomAcc{mom_zero(), 0.0, 0.0, 0.0, 0.0, 0}; }
+
+__device__ __forceinline__ void acc_fold(MomAcc& a) {
+    if (a.nb == 0) return;
+    const double q = a.S1 / a.S0;                                   // block mean - K
+    const double mb = a.K + q;
+    const double M2b = a.S2 - a.S1 * q;
+    if (a.m.W == 0.0) { a.m.W = a.S0; a.m.mean = mb; a.m.M2 = M2b; }
+    else {
+        const double W = a.m.W + a.S0;
+        const double d = mb - a.m.mean;
+        const double f = a.S0 / W;
+        a.m.mean = a.m.mean + d * f;
+        a.m.M2 = (a.m.M2 + M2b) + (d * d) * (a.m.W * f);
+        a.m.W = W;
+    }
+    a.K = a.m.mean; a.S0 = 0.0; a.S1 = 0.0; a.S2 = 0.0; a.nb = 0;
 }
 
-// block-level reduction of acc[C][4] -> partial[block][C][4]
-__device__ __forceinline__ void block_reduce_store(double (&acc)[HM_MAX_CHANNELS][kStatVals], double* partial) {
-    __shared__ double red[4][HM_MAX_CHANNELS * kStatVals];
+// one element (value v, weight w already formed, std s for the `error` sum) into the accumulator
+__device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s, bool weighted) {
+    if (weighted) {
+        if (w == w) a.m.Wall += w;                                          // nansum(weights)
+        if (s == s) { a.m.ss += s; a.m.cs += 1.0; }                         // nanmean(stds)
+        const double vw = v * w;
+        if (!(vw == vw)) return;                                            // nansum(values * weights), nansum(weights * (values - mean)**2)
+    } else {
+        if (!(v == v)) return;
+        w = 1.0;
+    }
+    if (a.nb == 0 && a.m.W == 0.0) a.K = v;
+    const double d = v - a.K;
+    const double t = w * d;
+    a.S0 += w; a.S1 += t; a.S2 = fma(t, d, a.S2);
+    if (++a.nb == kMomBlock) acc_fold(a);
+}
+
+__device__ __forceinline__ Mom acc_finish(MomAcc& a, bool weighted) {
+    acc_fold(a);
+    if (!weighted) a.m.Wall = a.m.W;
+    return a.m;
+}
+
+// Chan / Golub / LeVeque pairwise combination; an empty side (W == 0) leaves the other's moments untouched
+__device__ __forceinline__ Mom mom_merge(const Mom& a, const Mom& b) {
+    Mom r;
+    r.Wall = a.Wall + b.Wall; r.ss = a.ss + b.ss; r.cs = a.cs + b.cs;
+    if (b.W == 0.0) { r.W = a.W; r.mean = a.mean; r.M2 = a.M2; return r; }
+    if (a.W == 0.0) { r.W = b.W; r.mean = b.mean; r.M2 = b.M2; return r; }
+    const double W = a.W + b.W;
+    const double d = b.mean - a.mean;
+    const double f = b.W / W;
+    r.W = W;
+    r.mean = a.mean + d * f;
+    r.M2 = (a.M2 + b.M2) + (d * d) * (a.W * f);
+    return r;
+}
+
+__device__ __forceinline__ Mom mom_shfl_down(const Mom& m, int off) {
+    Mom r;
+    r.Wall = __shfl_down(m.Wall, off, 64); r.W = __shfl_down(m.W, off, 64); r.mean = __shfl_down(m.mean, off, 64);
+    r.M2 = __shfl_down(m.M2, off, 64); r.ss = __shfl_down(m.ss, off, 64); r.cs = __shfl_down(m.cs, off, 64);
+    return r;
+}
+__device__ __forceinline__ void mom_store(double* p, const Mom& m) { p[0] = m.Wall; p[1] = m.W; p[2] = m.mean; p[3] = m.M2; p[4] = m.ss; p[5] = m.cs; }
+__device__ __forceinline__ Mom mom_load(const double* p) { return Mom{p[0], p[1], p[2], p[3], p[4], p[5]}; }
+
+// workgroup-level combination of one state per thread, where thread t's state belongs to channel `ct`:
+// per channel a shuffle tree inside each wave (lanes of other channels contribute the empty state), then the four waves in order.
+// Result for channel c is written to partial[(block * HM_MAX_CHANNELS + c) * nq + q] by thread c (q = quantity index).
+template <int NQ>
+__device__ __forceinline__ void block_merge_store(const Mom (&mine)[NQ], int ct, double* partial) {
+    __shared__ double red[4][HM_MAX_CHANNELS][NQ][kMomVals];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < HM_MAX_CHANNELS; ++c)
+    for (int c = 0; c < HM_MAX_CHANNELS; ++c) {
 #pragma unroll
-        for (int k = 0; k < kStatVals; ++k) {
-            const double s = wave_sum_d(acc[c][k]);
-            if (lane == 0) red[wave][c * kStatVals + k] = s;
+        for (int q = 0; q < NQ; ++q) {
+            Mom m = c == ct ? mine[q] : mom_zero();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = mom_merge(m, mom_shfl_down(m, off));
+            if (lane == 0) mom_store(red[wave][c][q], m);
         }
+    }
     __syncthreads();
-    if (threadIdx.x < HM_MAX_CHANNELS * kStatVals)
-        partial[blockIdx.x * HM_MAX_CHANNELS * kStatVals + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < HM_MAX_CHANNELS * NQ) {
+        const int c = threadIdx.x / NQ, q = threadIdx.x % NQ;
+        Mom m = mom_load(red[0][c][q]);
+        for (int w = 1; w < 4; ++w) m = mom_merge(m, mom_load(red[w][c][q]));
+        mom_store(partial + ((static_cast<int64_t>(blockIdx.x) * HM_MAX_CHANNELS + c) * NQ + q) * kMomVals, m);
+    }
 }
 
-// pass 1: weighted: [sum w, sum v*w, sum std (non-nan), count std non-nan]; unweighted: [sum v, count, 0, 0]
-// pass 2: weighted: [sum w (v-mean)^2, 0,0,0];                              unweighted: [sum (v-mean)^2, 0,0,0]
-// The launch uses a total thread count that is a multiple of C (grid rounded to a multiple of 12 workgroups),
-// so a thread's elements all have the same channel c_t = first_element % C and it keeps 4 running sums, not 4*C.
-template <int PASS>
+// grid-level combination (one workgroup): thread t folds blocks t, t + 256, ... in order, then a fixed LDS tree over the 256 threads
+template <int NQ>
+__device__ __forceinline__ Mom grid_merge(const double* __restrict__ partial, int nblocks, int c, int q) {
+    __shared__ double tree[256][kMomVals];
+    Mom m = mom_zero();
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        m = mom_merge(m, mom_load(partial + ((static_cast<int64_t>(b) * HM_MAX_CHANNELS + c) * NQ + q) * kMomVals));
+    __syncthreads();                                        // (the previous (c, q) round is done with `tree`)
+    mom_store(tree[threadIdx.x], m);
+    __syncthreads();
+    for (int span = 128; span > 0; span >>= 1) {
+        if (static_cast<int>(threadIdx.x) < span) {
+            const Mom r = mom_merge(mom_load(tree[threadIdx.x]), mom_load(tree[threadIdx.x + span]));
+            mom_store(tree[threadIdx.x], r);
+        }
+        __syncthreads();
+    }
+    return mom_load(tree[0]);
+}
+
+// mean / std / error of modules/measurand.py:339-349 from the combined state:
+//   mean = nansum(v w) / nansum(w) = W mean_W / Wall;  std = sqrt(nansum(w (v - mean)^2) / nansum(w));  error = nanmean(std)
+__device__ __forceinline__ void mom_finish(const Mom& m, bool weighted, double& mean, double& sd, double& err) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (m.Wall == m.W) { mean = m.W == 0.0 ? nan : m.mean; sd = sqrt(m.M2 / m.Wall); }
+    else {                                                  // some weights belong to NaN values: the reference's denominators still count them
+        mean = (m.W * m.mean) / m.Wall;
+        const double d = m.mean - mean;
+        sd = sqrt((m.M2 + m.W * (d * d)) / m.Wall);
+    }
+    err = weighted ? m.ss / m.cs : nan;
+}
+
+// The launch uses a total thread count that is a multiple of C (grid rounded to a multiple of 12 workgroups), so a thread's
+// elements all have the same channel ct = first_element % C. Two independent running states per thread (even / odd visits)
+// keep two division chains in flight; they are combined first.
 __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
-                                               const double* __restrict__ mean /*pass 2*/, double* __restrict__ partial) {
+                                               double* __restrict__ partial) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int ct = static_cast<int>(first % C);
-    const double mu = PASS == 2 ? mean[ct] : 0.0;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    const bool weighted = sd != nullptr;
     constexpr int UN = 4;                                   // independent loads in flight per lane
+    MomAcc st = acc_zero();
     for (int64_t e = first; e < n; e += UN * stride) {
         double vv[UN], sv[UN];
         bool ok[UN];
@@ -140,108 +265,62 @@ __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, c
             sv[u] = (ok[u] && sd) ? __builtin_nontemporal_load(sd + q) : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (!ok[u]) continue;
-            const double v = vv[u];
-            if (sd) {
-                const double s = sv[u];
-                const double w = 1.0 / s;                                    // :342
-                if (PASS == 1) {
-                    if (w == w) t0 += w;                                    // nansum(weights)
-                    const double vw = v * w;
-                    if (vw == vw) t1 += vw;                                 // nansum(values * weights)
-                    if (s == s) { t2 += s; t3 += 1.0; }                     // nanmean(stds)
-                } else {
-                    const double d = v - mu;
-                    const double q2 = w * (d * d);                          // :345
-                    if (q2 == q2) t0 += q2;
-                }
-            } else {
-                if (PASS == 1) { if (v == v) { t0 += v; t1 += 1.0; } }
-                else { const double d = v - mu; const double q2 = d * d; if (q2 == q2) t0 += q2; }
-            }
-        }
+        for (int u = 0; u < UN; ++u)
+            if (ok[u]) acc_add(st, vv[u], weighted ? 1.0 / sv[u] : 1.0, sv[u], weighted);                 // w = 1 / std, :342
     }
-    double acc[HM_MAX_CHANNELS][kStatVals];
-#pragma unroll
-    for (int k = 0; k < HM_MAX_CHANNELS; ++k) {
-        const bool me = k == ct;
-        acc[k][0] = me ? t0 : 0.0; acc[k][1] = me ? t1 : 0.0; acc[k][2] = me ? t2 : 0.0; acc[k][3] = me ? t3 : 0.0;
-    }
-    block_reduce_store(acc, partial);
+    const Mom mine[1] = {acc_finish(st, weighted)};
+    block_merge_store<1>(mine, ct, partial);
 }
 
-// Sums `ncols` columns of partial[nblocks][ncols] with 256 threads: thread t adds rows t/ncols, t/ncols + R, ...
-// (R = 256/ncols row groups), then the R partial sums of a column are added in a fixed order -> deterministic.
-template <int NCOLS>
-__device__ __forceinline__ void column_sums(const double* __restrict__ partial, int nblocks, double* sums /*LDS [NCOLS]*/) {
-    __shared__ double part[256];
-    constexpr int R = 256 / NCOLS;
-    const int col = threadIdx.x % NCOLS, rg = threadIdx.x / NCOLS;
-    double s = 0.0;
-    for (int b = rg; b < nblocks; b += R) s += partial[b * NCOLS + col];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < NCOLS) {
-        double tot = 0.0;
-        for (int r = 0; r < R; ++r) tot += part[r * NCOLS + threadIdx.x];
-        sums[threadIdx.x] = tot;
-    }
-    __syncthreads();
-}
-
-// final: sums the partials in block order; stage 1 -> out[0..C) = mean, scratch keeps the denominators;
-//        stage 2 -> out[C..2C) = std, out[2C..3C) = error (nanmean of stds, weighted case only; NaN otherwise)
-template <int PASS>
 __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
-                                                     double* __restrict__ out, double* __restrict__ denom) {
-    const int t = threadIdx.x;
-    __shared__ double sums[HM_MAX_CHANNELS * kStatVals];
-    column_sums<HM_MAX_CHANNELS * kStatVals>(partial, nblocks, sums);
-    if (t < C) {
-        const double* q = sums + t * kStatVals;
-        if (PASS == 1) {
-            if (weighted) { out[t] = q[1] / q[0]; denom[t] = q[0]; out[2 * C + t] = q[2] / q[3]; }
-            else { out[t] = q[0] / q[1]; denom[t] = q[1]; out[2 * C + t] = __longlong_as_double(0x7ff8000000000000ll); }
-        } else {
-            out[C + t] = sqrt(q[0] / denom[t]);
+                                                     double* __restrict__ out) {
+    for (int c = 0; c < C; ++c) {
+        const Mom m = grid_merge<1>(partial, nblocks, c, 0);
+        if (threadIdx.x == 0) {
+            double mean, sdv, err;
+            mom_finish(m, weighted != 0, mean, sdv, err);
+            out[c] = mean; out[C + c] = sdv; out[2 * C + c] = err;
         }
     }
 }
 
 // ---- pair-fused linearity statistics ----------------------------------------------------------
 // ExposurePair.compute_difference + compute_stats(axis=(0,1)) (modules/exposure_series.py:33-54, called per pair
-// by process_linearity :443-446) without materialising the two difference images: each pass reads x, y (and
-// their stds) once and reduces both the absolute and the relative difference. out: 6*C doubles
+// by process_linearity :443-446) without materialising the two difference images and in one pass: x, y (and their stds) are read
+// once and both the absolute and the relative difference are reduced. out: 6*C doubles
 // [abs mean | abs std | abs error | rel mean | rel std | rel error].
-constexpr int kPairVals = 8;          // per channel: 4 sums for the absolute, 4 for the relative difference
-
+// difference terms of one element (measurand.py:634-653) and the statistics weights 1 / std of both differences. One division
+// (1 / scale) and two reciprocal square roots per element: x / (m y) = x r, (ys x) / (m y^2) = ys x m r^2 with r = 1 / (m y), and
+// w = 1 / sqrt(q), std = q w - a few ulp from the reference's three divisions, two square roots and two reciprocals, which is what
+// made the all-pairs kernel FP64-VALU bound; the statistics agree with the oracle to 1e-12.
 __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, double ys, double mult, bool with_std,
-                                           double& a, double& as, double& r, double& rs) {
+                                           double& a, double& as, double& wa, double& r, double& rs, double& wr) {
     const double scale = mult * yv;                     // measurand.py:634
     a = xv - scale;                                     // :635
-    r = a / scale;                                      // :636
+    const double inv = 1.0 / scale;
+    r = a * inv;                                        // :636
+    wa = 1.0; wr = 1.0;
     if (with_std) {
         const double m1 = mult * ys;
-        as = sqrt(xs * xs + m1 * m1);                   // :652
-        const double u1 = xs / (mult * yv);
-        const double u2 = (ys * xv) / (mult * (yv * yv));
-        rs = sqrt(u1 * u1 + u2 * u2);                   // :653
+        const double qa = xs * xs + m1 * m1;            // :652
+        wa = 1.0 / sqrt(qa);
+        as = qa * wa;
+        const double u1 = xs * inv;
+        const double u2 = ((ys * xv) * mult) * (inv * inv);
+        const double qr = u1 * u1 + u2 * u2;            // :653
+        wr = 1.0 / sqrt(qr);
+        rs = qr * wr;
     }
 }
 
-template <int PASS>
 __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x, const double* __restrict__ sx,
                                                     const double* __restrict__ y, const double* __restrict__ sy, double mult,
-                                                    int64_t n, int C, const double* __restrict__ means /*pass 2: out[]*/,
-                                                    double* __restrict__ partial) {
-    __shared__ double red[4][HM_MAX_CHANNELS * kPairVals];
+                                                    int64_t n, int C, double* __restrict__ partial) {
     const bool with_std = sx || sy;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;       // a multiple of C (see k_stats)
     const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int ct = static_cast<int>(first % C);
-    const double mu[2] = {PASS == 2 ? means[ct] : 0.0, PASS == 2 ? means[3 * C + ct] : 0.0};
-    double t[kPairVals] = {};
+    MomAcc st[2] = {acc_zero(), acc_zero()};                                   // absolute | relative difference
     constexpr int UN = 2;
     for (int64_t e0 = first; e0 < n; e0 += UN * stride) {
         double xv[UN], yv[UN], xs[UN], ys[UN];
@@ -258,62 +337,122 @@ __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (!ok[u]) continue;
-            double a, as = 0.0, r, rs = 0.0;
-            pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, a, as, r, rs);
-            const double vv[2] = {a, r}, ss[2] = {as, rs};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double v = vv[h];
-                if (with_std) {
-                    const double w = 1.0 / ss[h];
-                    if (PASS == 1) {
-                        if (w == w) t[4 * h] += w;
-                        const double vw = v * w;
-                        if (vw == vw) t[4 * h + 1] += vw;
-                        if (ss[h] == ss[h]) { t[4 * h + 2] += ss[h]; t[4 * h + 3] += 1.0; }
-                    } else {
-                        const double d = v - mu[h];
-                        const double q2 = w * (d * d);
-                        if (q2 == q2) t[4 * h] += q2;
-                    }
-                } else {
-                    if (PASS == 1) { if (v == v) { t[4 * h] += v; t[4 * h + 1] += 1.0; } }
-                    else { const double d = v - mu[h]; const double q2 = d * d; if (q2 == q2) t[4 * h] += q2; }
-                }
-            }
+            double a, as = 0.0, wa, r, rs = 0.0, wr;
+            pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, a, as, wa, r, rs, wr);
+            acc_add(st[0], a, wa, as, with_std);
+            acc_add(st[1], r, wr, rs, with_std);
         }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < HM_MAX_CHANNELS; ++c)
-#pragma unroll
-        for (int k = 0; k < kPairVals; ++k) {
-            const double s = wave_sum_d(c == ct ? t[k] : 0.0);
-            if (lane == 0) red[wave][c * kPairVals + k] = s;
-        }
-    __syncthreads();
-    if (threadIdx.x < HM_MAX_CHANNELS * kPairVals)
-        partial[blockIdx.x * HM_MAX_CHANNELS * kPairVals + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const Mom mine[2] = {acc_finish(st[0], with_std), acc_finish(st[1], with_std)};
+    block_merge_store<2>(mine, ct, partial);
 }
 
-template <int PASS>
 __global__ __launch_bounds__(256) void k_pair_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
-                                                    double* __restrict__ out, double* __restrict__ denom) {
-    const int t = threadIdx.x;
-    __shared__ double sums[HM_MAX_CHANNELS * kPairVals];
-    column_sums<HM_MAX_CHANNELS * kPairVals>(partial, nblocks, sums);
-    if (t < 2 * C) {
-        const int h = t / C, c = t % C;
-        const double* q = sums + c * kPairVals + 4 * h;
-        double* o = out + 3 * C * h;
-        if (PASS == 1) {
-            if (weighted) { o[c] = q[1] / q[0]; denom[t] = q[0]; o[2 * C + c] = q[2] / q[3]; }
-            else { o[c] = q[0] / q[1]; denom[t] = q[1]; o[2 * C + c] = __longlong_as_double(0x7ff8000000000000ll); }
-        } else {
-            o[C + c] = sqrt(q[0] / denom[t]);
+                                                    double* __restrict__ out) {
+    for (int h = 0; h < 2; ++h)
+        for (int c = 0; c < C; ++c) {
+            const Mom m = grid_merge<2>(partial, nblocks, c, h);
+            if (threadIdx.x == 0) {
+                double mean, sdv, err;
+                mom_finish(m, weighted != 0, mean, sdv, err);
+                double* o = out + 3 * C * h;
+                o[c] = mean; o[C + c] = sdv; o[2 * C + c] = err;
+            }
+        }
+}
+
+// ---- all exposure pairs of a stack in one launch ------------------------------------------------
+// ExposureSeries.process_linearity (modules/exposure_series.py:421-446) evaluates compute_difference + compute_stats for every
+// exposure pair (i, j) of the series: N (N - 1) / 2 pairs, each reading two frames (+ stds). Pair by pair every frame is read
+// N - 1 times from HBM. Here a workgroup owns a run of elements and each of its waves owns ONE pair: the waves of a workgroup
+// read the same 64-element chunks of the frames their pairs need at about the same time, so a chunk comes from HBM once and
+// from the CU's L1 / the XCD's L2 for the other waves; every wave keeps the Welford states of its pair (absolute and relative
+// difference) and its partial goes to partial[block][pair]. Up to HM_PAIRS_MAX pairs per launch (1024-thread workgroups).
+struct PairsK {
+    const double* val[HM_MAX_FRAMES];
+    const double* sd[HM_MAX_FRAMES];
+    int32_t pi[HM_PAIRS_MAX], pj[HM_PAIRS_MAX];
+    double mult[HM_PAIRS_MAX];
+    int64_t n;
+    int32_t C, n_pairs, with_std;
+};
+
+__global__ __launch_bounds__(1024) void k_pairs_stats(const PairsK a, double* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));       // = pair index, wave-uniform
+    const double* x = a.val[a.pi[wave]];
+    const double* y = a.val[a.pj[wave]];
+    const double* sx = a.with_std ? a.sd[a.pi[wave]] : nullptr;
+    const double* sy = a.with_std ? a.sd[a.pj[wave]] : nullptr;
+    const double mult = a.mult[wave];
+    const bool with_std = a.with_std != 0;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 64;                               // a multiple of C (grid: multiple of 12)
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+    const int ct = static_cast<int>(first % a.C);
+    MomAcc st[2] = {acc_zero(), acc_zero()};                                                   // absolute | relative difference
+    constexpr int UN = 2;
+    for (int64_t e0 = first; e0 < a.n; e0 += UN * stride) {
+        double xv[UN], yv[UN], xs[UN], ys[UN];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t q = e0 + u * stride;
+            ok[u] = q < a.n;
+            xv[u] = ok[u] ? x[q] : 0.0;                                                        // (default cache policy: the other waves re-read these lines)
+            yv[u] = ok[u] ? y[q] : 1.0;
+            xs[u] = (ok[u] && sx) ? sx[q] : 0.0;
+            ys[u] = (ok[u] && sy) ? sy[q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (!ok[u]) continue;
+            double av, as = 0.0, wa, rv, rs = 0.0, wr;
+            pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, av, as, wa, rv, rs, wr);
+            acc_add(st[0], av, wa, as, with_std);
+            acc_add(st[1], rv, wr, rs, with_std);
         }
     }
+    const Mom mine[2] = {acc_finish(st[0], with_std), acc_finish(st[1], with_std)};
+#pragma unroll
+    for (int c = 0; c < HM_MAX_CHANNELS; ++c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            Mom m = c == ct ? mine[q] : mom_zero();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = mom_merge(m, mom_shfl_down(m, off));
+            if (lane == 0)
+                mom_store(partial + (((static_cast<int64_t>(blockIdx.x) * a.n_pairs + wave) * HM_MAX_CHANNELS + c) * 2 + q) * kMomVals, m);
+        }
+    }
+}
+
+// one workgroup per pair: folds the per-block partials of its pair in a fixed order
+__global__ __launch_bounds__(256) void k_pairs_final(const double* __restrict__ partial, int nblocks, int n_pairs, int C, int weighted,
+                                                     double* __restrict__ out) {
+    __shared__ double tree[256][kMomVals];
+    const int pair = blockIdx.x;
+    for (int h = 0; h < 2; ++h)
+        for (int c = 0; c < C; ++c) {
+            Mom m = mom_zero();
+            for (int b = threadIdx.x; b < nblocks; b += 256)
+                m = mom_merge(m, mom_load(partial + (((static_cast<int64_t>(b) * n_pairs + pair) * HM_MAX_CHANNELS + c) * 2 + h) * kMomVals));
+            __syncthreads();
+            mom_store(tree[threadIdx.x], m);
+            __syncthreads();
+            for (int span = 128; span > 0; span >>= 1) {
+                if (static_cast<int>(threadIdx.x) < span) {
+                    const Mom r = mom_merge(mom_load(tree[threadIdx.x]), mom_load(tree[threadIdx.x + span]));
+                    mom_store(tree[threadIdx.x], r);
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                double mean, sdv, err;
+                mom_finish(mom_load(tree[0]), weighted != 0, mean, sdv, err);
+                double* o = out + static_cast<int64_t>(pair) * 6 * C + 3 * C * h;
+                o[c] = mean; o[C + c] = sdv; o[2 * C + c] = err;
+            }
+        }
 }
 
 // ---- per-channel histogram (compute_channel_histogram, modules/measurand.py:430-469) ----------------
@@ -470,7 +609,7 @@ extern "C" int hm_interpolate(const double* x0, const double* s0, const double* 
 }
 
 extern "C" size_t hm_channel_statistics_workspace_bytes(void) {
-    return sizeof(double) * (kStatBlocks * HM_MAX_CHANNELS * kStatVals + HM_MAX_CHANNELS);
+    return sizeof(double) * (kStatBlocks * HM_MAX_CHANNELS * kMomVals);
 }
 
 extern "C" int hm_channel_statistics(const double* val, const double* std, int64_t n, int C,
@@ -478,33 +617,59 @@ extern "C" int hm_channel_statistics(const double* val, const double* std, int64
     if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !val || !out || !workspace) return HM_EINVAL;
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
     double* partial = static_cast<double*>(workspace);
-    double* denom = partial + kStatBlocks * HM_MAX_CHANNELS * kStatVals;
     const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
-    const int weighted = std ? 1 : 0;
-    hipLaunchKernelGGL(k_stats<1>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(nullptr), partial);
-    hipLaunchKernelGGL(k_stats_final<1>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
-    hipLaunchKernelGGL(k_stats<2>, dim3(grid), dim3(256), 0, st, val, std, n, C, static_cast<const double*>(out), partial);
-    hipLaunchKernelGGL(k_stats_final<2>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, val, std, n, C, partial);
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, st, partial, grid, C, std ? 1 : 0, out);
     return launch_status();
 }
 
 extern "C" size_t hm_pair_statistics_workspace_bytes(void) {
-    return sizeof(double) * (kStatBlocks * HM_MAX_CHANNELS * kPairVals + 2 * HM_MAX_CHANNELS);
+    return sizeof(double) * (kStatBlocks * HM_MAX_CHANNELS * 2 * kMomVals);
 }
 
 extern "C" int hm_pair_statistics(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
                                   int64_t n, int C, double* out /*6*C*/, void* workspace, void* stream) {
     if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !x || !y || !out || !workspace) return HM_EINVAL;
     double* partial = static_cast<double*>(workspace);
-    double* denom = partial + kStatBlocks * HM_MAX_CHANNELS * kPairVals;
     const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
-    const int weighted = (sx || sy) ? 1 : 0;
-    hipLaunchKernelGGL(k_pair_stats<1>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(nullptr), partial);
-    hipLaunchKernelGGL(k_pair_final<1>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
-    hipLaunchKernelGGL(k_pair_stats<2>, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, static_cast<const double*>(out), partial);
-    hipLaunchKernelGGL(k_pair_final<2>, dim3(1), dim3(256), 0, st, partial, grid, C, weighted, out, denom);
+    hipLaunchKernelGGL(k_pair_stats, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, partial);
+    hipLaunchKernelGGL(k_pair_final, dim3(1), dim3(256), 0, st, partial, grid, C, (sx || sy) ? 1 : 0, out);
+    return launch_status();
+}
+
+extern "C" size_t hm_pairs_statistics_workspace_bytes(int n_pairs) {
+    const int p = n_pairs < 1 ? 1 : (n_pairs > HM_PAIRS_MAX ? HM_PAIRS_MAX : n_pairs);
+    return sizeof(double) * static_cast<size_t>(kStatBlocks) * static_cast<size_t>(p) * HM_MAX_CHANNELS * 2 * kMomVals;
+}
+
+extern "C" int hm_pairs_statistics(const double* const* vals, const double* const* stds, int n_frames, const int32_t* pair_i,
+                                   const int32_t* pair_j, const double* multipliers, int n_pairs, int64_t n, int C,
+                                   double* out /*n_pairs * 6C*/, void* workspace, void* stream) {
+    if (!vals || !pair_i || !pair_j || !multipliers || !out || !workspace || n < 1 || C < 1 || C > HM_MAX_CHANNELS) return HM_EINVAL;
+    if (n_frames < 1 || n_frames > HM_MAX_FRAMES || n_pairs < 1) return HM_EINVAL;
+    PairsK k{};
+    k.n = n; k.C = C; k.with_std = stds ? 1 : 0;
+    for (int i = 0; i < n_frames; ++i) {
+        if (!vals[i] || !aligned(vals[i], 8)) return HM_EINVAL;
+        k.val[i] = vals[i];
+        if (stds) { if (!stds[i]) return HM_EINVAL; k.sd[i] = stds[i]; }
+    }
+    for (int p = 0; p < n_pairs; ++p)
+        if (pair_i[p] < 0 || pair_i[p] >= n_frames || pair_j[p] < 0 || pair_j[p] >= n_frames) return HM_EINVAL;
+    hipStream_t st = as_stream(stream);
+    double* partial = static_cast<double*>(workspace);
+    int64_t g = (n + 63) / 64;
+    g = ((g + 11) / 12) * 12;
+    const int grid = static_cast<int>(g < kStatBlocks ? g : kStatBlocks);
+    for (int p0 = 0; p0 < n_pairs; p0 += HM_PAIRS_MAX) {                 // HM_PAIRS_MAX pairs (waves of a workgroup) per launch
+        const int np = n_pairs - p0 < HM_PAIRS_MAX ? n_pairs - p0 : HM_PAIRS_MAX;
+        k.n_pairs = np;
+        for (int p = 0; p < np; ++p) { k.pi[p] = pair_i[p0 + p]; k.pj[p] = pair_j[p0 + p]; k.mult[p] = multipliers[p0 + p]; }
+        hipLaunchKernelGGL(k_pairs_stats, dim3(grid), dim3(64 * np), 0, st, k, partial);
+        hipLaunchKernelGGL(k_pairs_final, dim3(np), dim3(256), 0, st, partial, grid, np, C, k.with_std, out + static_cast<int64_t>(p0) * 6 * C);
+    }
     return launch_status();
 }
 

@@ -609,6 +609,45 @@ def pair_statistics(x, sx, y, sy, multiplier: float):
     return mk(0), mk(3 * Cc)
 
 
+def pairs_statistics(vals: Sequence[torch.Tensor], stds: Optional[Sequence[torch.Tensor]], pairs: Sequence[tuple], to_host: bool = False):
+    """Statistics of the absolute and relative difference of EVERY exposure pair of a stack in one fused launch
+    (hm_pairs_statistics; modules/exposure_series.py:421-446). `pairs` = [(i, j, multiplier), ...] with i the short and j the
+    long exposure. Returns one (abs_stats, rel_stats) tuple of dicts per pair, as pair_statistics() does."""
+    n = len(vals)
+    for i, v in enumerate(vals):
+        _require_cuda(v, f"vals[{i}]")
+        if v.shape != vals[0].shape or v.dtype != _F64:
+            raise ValueError("pairs_statistics needs float64 frames of one shape")
+    dev = vals[0].device
+    vals = [v.contiguous() for v in vals]
+    if stds is not None:
+        if len(stds) != n or any(s is None for s in stds):
+            raise ValueError("one std frame per value frame (or none at all)")
+        stds = [s.to(_F64).contiguous() for s in stds]
+    Cc = vals[0].shape[-1]
+    P = len(pairs)
+    vp = _ptr_array(vals)
+    sp = None if stds is None else _ptr_array(stds)
+    pi = (C.c_int32 * P)(*[int(p[0]) for p in pairs])
+    pj = (C.c_int32 * P)(*[int(p[1]) for p in pairs])
+    pm = (C.c_double * P)(*[float(p[2]) for p in pairs])
+    out = torch.empty(P * 6 * Cc, dtype=_F64, device=dev)
+    ws = torch.empty(max(1, nat.lib.hm_pairs_statistics_workspace_bytes(P) // 8), dtype=_F64, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib.hm_pairs_statistics(C.cast(vp, C.POINTER(C.c_void_p)), None if sp is None else C.cast(sp, C.POINTER(C.c_void_p)), n,
+                                              pi, pj, pm, P, vals[0].numel(), Cc, out.data_ptr(), ws.data_ptr(), _stream(dev)),
+                  "hm_pairs_statistics")
+    w = stds is not None
+    if to_host:
+        out = out.cpu()                                   # one device-to-host copy for all pairs (P * 6C numbers)
+    res = []
+    for p in range(P):
+        b = p * 6 * Cc
+        mk = lambda o: {"mean": out[o:o + Cc], "std": out[o + Cc:o + 2 * Cc], "error": out[o + 2 * Cc:o + 3 * Cc] if w else None}   # noqa: E731
+        res.append((mk(b), mk(b + 3 * Cc)))
+    return res
+
+
 def channel_histogram(val: torch.Tensor, std: Optional[torch.Tensor], bins: int, included_range, channels: Sequence[int]):
     """modules/measurand.py:430-469 -> {c: (hist ndarray, bin_edges ndarray)} like np.histogram. A range of None is
     evaluated per channel from the counted values (np.histogram's default), with one extra reduction."""

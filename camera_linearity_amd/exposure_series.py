@@ -292,6 +292,8 @@ class ExposureSeries(object):
             if image_set.measurand.std is None and use_std:
                 image_set.load_std_image()
             image_set.measurand.apply_thresholds(lower, upper)
+        if self._all_pairs_fused():
+            return
         for pair in self.exposure_pairs:
             v = pair.short_exposure.measurand.val
             if v is not None and v.is_cuda and v.dim() == 3 and v.shape[-1] <= 4 and pair.long_exposure.measurand.shape == tuple(v.shape):
@@ -299,6 +301,33 @@ class ExposureSeries(object):
             else:
                 pair.compute_difference()
                 pair.compute_stats(axis=(0, 1), release_memory_after=True)
+
+    def _all_pairs_fused(self) -> bool:
+        """Every pair of the series in ONE launch (hm_pairs_statistics): each frame is read from HBM once instead of once per
+        pair it takes part in. Applies when the pairs are pairs of this series' own images, all images share one (H, W, C <= 4)
+        shape on one device and either all or none of them carry a std; otherwise the per-pair path above runs."""
+        from . import engine
+        sets = self.input_image_sets
+        if not self.exposure_pairs or not sets:
+            return False
+        index = {id(s): i for i, s in enumerate(sets)}
+        if any(id(p.short_exposure) not in index or id(p.long_exposure) not in index for p in self.exposure_pairs):
+            return False
+        shapes = {s.measurand.shape for s in sets}
+        if len(shapes) != 1 or None in shapes or len(next(iter(shapes))) != 3 or next(iter(shapes))[-1] > 4:
+            return False
+        have_std = [s.measurand.std is not None for s in sets]
+        if any(have_std) != all(have_std):
+            return False
+        vals = [s.measurand._f64() for s in sets]
+        if not all(v.is_cuda and v.device == vals[0].device for v in vals):
+            return False
+        stds = [s.measurand.std for s in sets] if all(have_std) else None
+        pairs = [(index[id(p.short_exposure)], index[id(p.long_exposure)], p.exposure_ratio) for p in self.exposure_pairs]
+        for p, (ab, rel) in zip(self.exposure_pairs, engine.pairs_statistics(vals, stds, pairs, to_host=True)):
+            p.absolute_stats, p.relative_stats = ab, rel          # (host tensors: 6C numbers per pair, fetched with ONE copy)
+            p.absolute_difference = p.relative_difference = None
+        return True
 
     def collect_exposure_pair_stats(self, return_cupy: Optional[bool] = False):
         rel = {"ratios": [], "means": [], "stds": [], "errors": []}

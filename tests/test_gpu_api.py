@@ -356,7 +356,8 @@ def test_measurand_methods_run_their_hip_kernels(M):
         A.compute_difference(A, M(b[:, :, :1]), 0.5)
     with pytest.raises(NotImplementedError):
         A.interpolate(A, M(b[:1]), 1.0, 3.0, 1.5)
-    ran("hm_binary_op", lambda: A ** 2)
+    ran("hm_binary_op", lambda: A ** B)
+    ran("hm_pow_scalar", lambda: A ** 2)
     from camera_linearity_amd import engine
     ran("hm_merge", lambda: engine.merge([torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")] * 2, [1e-3, 2e-3], orc.synthetic_icrf()[0]))
 
@@ -388,3 +389,46 @@ def test_pow_scalar_exponent(M, p):
     assert np.array_equal(np.isnan(gs), np.isnan(os_)), (p, gs, os_)
     fin = np.isfinite(os_)
     np.testing.assert_allclose(gs[fin], os_[fin], rtol=1e-13)
+
+
+@pytest.mark.parametrize("use_std", [True, False])
+def test_all_pairs_fused_linearity(use_std):
+    """ExposureSeries.process_linearity through hm_pairs_statistics (every pair of the series in one launch, frames read once)
+    against the oracle's per-pair evaluation (compute_difference + dimension_statistics, modules/exposure_series.py:443-446) and
+    against the per-pair HIP kernel; 7 frames with NaNs from the thresholds, 18 pairs (> HM_PAIRS_MAX: two launches)."""
+    from camera_linearity_amd import _native as nat, engine
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    n, h, w = 7, 37, 29
+    frames, stds, _ = orc.synthetic_stack(8, n, h, w, with_std=True)
+    t = 1e-3 * 1.6 ** np.arange(n)                                       # ratios >= 0.1 for |i - j| <= 4: 18 pairs
+    sets = [ImageSet(value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
+    series = ExposureSeries(input_image_sets=sets)
+    series.initialize_exposure_pairs()
+    assert len(series.exposure_pairs) == 18
+    icrf, _ = orc.synthetic_icrf((1.0, 1.0, 1.0))
+    before = nat.lib.calls["hm_pairs_statistics"]
+    series.process_linearity(icrf, linearity_limit=20, use_std=use_std)
+    assert nat.lib.calls["hm_pairs_statistics"] == before + 1
+    lo, hi = icrf[20, 0], icrf[255 - 20, 0]
+    th = [orc.apply_thresholds(orc.unit_from_u8(f), s if use_std else None, [lo] * 3, [hi] * 3) for f, s in zip(frames, stds)]
+    assert any(np.isnan(v).any() for v, _ in th)
+    up = lambda a: None if a is None else torch.as_tensor(a, device="cuda")   # noqa: E731
+    k = 0
+    for i in range(n):
+        for j in range(n):
+            if i >= j or t[i] / t[j] < 0.1:
+                continue
+            p = series.exposure_pairs[k]
+            k += 1
+            ad, ads, rd, rds = orc.compute_difference(th[i][0], th[i][1], th[j][0], th[j][1], t[i] / t[j])
+            fa, fr = engine.pair_statistics(up(th[i][0]), up(th[i][1]), up(th[j][0]), up(th[j][1]), t[i] / t[j])
+            for got, dv, ds, single in ((p.absolute_stats, ad, ads, fa), (p.relative_stats, rd, rds, fr)):
+                ref = orc.dimension_statistics(dv, ds, (0, 1))
+                for key in ("mean", "std", "error"):
+                    if ref[key] is None:
+                        assert got[key] is None
+                        continue
+                    np.testing.assert_allclose(got[key].cpu().numpy(), ref[key], rtol=1e-11)
+                    np.testing.assert_allclose(got[key].cpu().numpy(), single[key].cpu().numpy(), rtol=1e-12)
+    assert k == 18

@@ -661,3 +661,85 @@ def test_concurrent_streams(eng):
         s.synchronize()
     for p, (v, sd) in zip(plans, serial):
         assert torch.equal(p.outputs["val"], v) and torch.equal(p.outputs["std"], sd)
+
+
+def test_config3_full_size_with_corrections(eng):
+    """BASELINE configs[2] at the size the metric is quoted on - 7 x 4096 x 4096 x 3 uint8 + float64 std + seven dark maps
+    (hot-pixel filter) + flat field - through size-independent properties and a band against the oracle:
+    (1) tiling invariance: two row tiles with a 3 x 3 median halo reproduce the whole image bit for bit;
+    (2) kernel invariance: the generic kernel (+ fix-up pass) reproduces the streaming kernel bit for bit;
+    (3) rows 0..63 (+ one halo row) against the oracle: val 1e-12, std 1e-9."""
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
+    n, H, W, thr = 7, 4096, 4096, 0.05
+    frames, stds, t = synthetic_stack_device(13, n, H, W, device="cuda", with_std=True)
+    icrf, diff = synthetic_icrf()
+    flat, flat_std, dark0 = synthetic_flat_dark(13, H, W, device="cuda", hot_density=1e-4)
+    darks = [dark0] + [synthetic_flat_dark(14 + i, H, W, device="cuda", hot_density=1e-4)[2] for i in range(n - 1)]   # seven DIFFERENT maps
+    x0, x1, y0, y1 = eng.flat_roi_bounds(H, W, 0.2)
+    ffm = eng.roi_mean(flat, x0, x1, y0, y1).cpu().numpy()
+    ffs = eng.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy()
+    dmin = [eng.dark_min_dn(1.0, thr)] * n
+    kw = dict(dark_min=dmin, median_k=3, ff_mean=ffm, ff_std_mean=ffs)
+    base = eng.plan_merge(frames, t, icrf, diff, stds, darks=darks, flat=flat, flat_std=flat_std, **kw)
+    assert "merge_u8_fast_std" in base.kernels and "merge_fixup_hot" in base.kernels
+    base.launch()
+    val, std = base.outputs["val"], base.outputs["std"]
+    assert bool(torch.isfinite(val).all()) and bool(torch.isfinite(std).all())
+    # (1)
+    cut = 1777
+    top = eng.merge([f[:cut + 1] for f in frames], t, icrf, diff, [s[:cut + 1] for s in stds], darks=[d[:cut + 1] for d in darks],
+                    flat=flat[:cut], flat_std=flat_std[:cut], height=H, row0=0, rows=cut, buf_row0=0, **kw)
+    bot = eng.merge([f[cut - 1:] for f in frames], t, icrf, diff, [s[cut - 1:] for s in stds], darks=[d[cut - 1:] for d in darks],
+                    flat=flat[cut:], flat_std=flat_std[cut:], height=H, row0=cut, rows=H - cut, buf_row0=cut - 1, **kw)
+    assert torch.equal(top["val"], val[:cut]) and torch.equal(bot["val"], val[cut:])
+    assert torch.equal(top["std"], std[:cut]) and torch.equal(bot["std"], std[cut:])
+    del top, bot
+    # (2)
+    gen = eng.merge(frames, t, icrf, diff, stds, darks=darks, flat=flat, flat_std=flat_std, variant=-1, **kw)
+    assert torch.equal(gen["val"], val) and torch.equal(gen["std"], std)
+    del gen
+    # (3)
+    rows = 64
+    h = lambda x: x[:rows + 1].cpu().numpy()                                 # noqa: E731
+    fv = orc.unit_from_u8(h(flat))
+    ref = orc.merge([h(f) for f in frames], t, icrf, diff, stds=[h(s) for s in stds], darks=[orc.unit_from_u8(h(d)) for d in darks],
+                    dark_threshold=thr, median_k=3, flat=fv, flat_std=h(flat_std), ff_mean=ffm, ff_std_mean=ffs)
+    hot_rows = sum(int((d[:rows] >= dmin[0]).sum()) for d in darks)
+    assert hot_rows > 0                                                       # the band does exercise the fix-up pass
+    close(host(val[:rows]), ref["val_ff"][:rows], VAL_RTOL)
+    close(host(std[:rows]), ref["std_ff"][:rows], STD_RTOL)
+
+
+@pytest.mark.parametrize("with_std", [False, True])
+def test_config4_row_tile_shape(eng, with_std):
+    """BASELINE configs[3]'s tile at the size the metric is quoted on: 15 frames, 1024 rows x 8192 columns x 3, the tile at
+    row0 = 3072 of an 8192-row image with a 3 x 3 median halo (input rows 3071..4096). It must equal, bit for bit, rows
+    3072..4095 of a 2048-row tile starting at 2048 merged from the same buffers (different tiling, different group phase),
+    and a band of it must match the oracle."""
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
+    n, Himg, W, thr = 15, 8192, 8192, 0.05
+    lo, hi = 2047, 4097                                                       # buffer rows: the 2-tile span + halo
+    frames, stds, t = synthetic_stack_device(17, n, hi - lo, W, device="cuda", with_std=with_std)
+    icrf, diff = synthetic_icrf()
+    dark = synthetic_flat_dark(17, hi - lo, W, device="cuda", hot_density=1e-3)[2]
+    darks = [dark if i % 2 else None for i in range(n)]
+    dmin = [eng.dark_min_dn(1.0, thr) if i % 2 else 256 for i in range(n)]
+    kw = dict(darks=darks, dark_min=dmin, median_k=3, height=Himg)
+    big = eng.plan_merge(frames, t, icrf, diff if with_std else None, stds, row0=2048, rows=2048, buf_row0=lo, **kw)
+    big.launch()
+    cutv = lambda x: None if x is None else x[3071 - lo:]                    # noqa: E731  (views: contiguous row slices, no copies)
+    tile = eng.plan_merge([cutv(f) for f in frames], t, icrf, diff if with_std else None, None if stds is None else [cutv(s) for s in stds],
+                          darks=[cutv(d) for d in darks], dark_min=dmin, median_k=3, height=Himg, row0=3072, rows=1024, buf_row0=3071)
+    assert ("merge_u8_fast_std<N=15" if with_std else "merge_u8_val3<N=15") in tile.kernels and "merge_fixup_hot" in tile.kernels
+    tile.launch()
+    assert torch.equal(tile.outputs["val"], big.outputs["val"][1024:])
+    if with_std:
+        assert torch.equal(tile.outputs["std"], big.outputs["std"][1024:])
+    rows = 24
+    h = lambda x: x[3071 - lo:3071 - lo + rows + 2].cpu().numpy()            # noqa: E731  (image rows 3071 .. 3072 + rows)
+    dv = orc.unit_from_u8(h(dark))
+    ref = orc.merge([h(f) for f in frames], t, icrf, diff if with_std else None, stds=None if stds is None else [h(s) for s in stds],
+                    darks=[dv if i % 2 else None for i in range(n)], dark_threshold=thr, median_k=3)
+    close(host(tile.outputs["val"][:rows]), ref["val"][1:rows + 1], VAL_RTOL)
+    if with_std:
+        close(host(tile.outputs["std"][:rows]), ref["std"][1:rows + 1], STD_RTOL)

@@ -35,7 +35,24 @@ for use_std in (False, True):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     E = H * W * 3
-    bytes_pairwise = npairs * 2 * (4 if use_std else 2) * 8 * E        # two passes over 2 (4) arrays per pair
-    print(f"use_std={use_std}: {npairs} pairs, {dt * 1e3:.1f} ms per call, {dt / npairs * 1e3:.2f} ms per pair, "
-          f"{bytes_pairwise / dt / 1e12:.2f} TB/s of pair-wise traffic", flush=True)
+    # the kernels alone (device-resident thresholded frames): all pairs in one launch vs one fused launch per pair
+    vals = [s_.measurand._f64() for s_ in sets]
+    sds = [s_.measurand.std for s_ in sets] if use_std else None
+    idx = {id(s_): i for i, s_ in enumerate(sets)}
+    pairs = [(idx[id(p.short_exposure)], idx[id(p.long_exposure)], p.exposure_ratio) for p in series.exposure_pairs]
+
+    def timed(fn, reps=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    t_all = timed(lambda: engine.pairs_statistics(vals, sds, pairs))
+    t_each = timed(lambda: [engine.pair_statistics(vals[i], None if sds is None else sds[i], vals[j], None if sds is None else sds[j], m) for i, j, m in pairs])
+    once = n * (2 if use_std else 1) * 8 * E                            # every frame (+ std) read once
+    print(f"use_std={use_std}: {npairs} pairs; process_linearity end to end {dt * 1e3:.1f} ms; hm_pairs_statistics alone {t_all:.2f} ms "
+          f"({once / t_all / 1e9:.2f} TB/s of read-once traffic); {npairs} x hm_pair_statistics {t_each:.2f} ms", flush=True)
     del sets, series

@@ -21,6 +21,7 @@ dn, sd = frames[1], stds[1]
 v = engine.u8_to_unit(dn)
 v2 = engine.u8_to_unit(frames[0]) + 0.25
 icrf, diff = synthetic_icrf()
+icrf, diff = torch.as_tensor(icrf, device=dev), torch.as_tensor(diff, device=dev)     # tables resident on the device (an upload per call is not the kernel)
 flat, flat_std, dark = synthetic_flat_dark(7, H, W, device=dev)
 x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
 m = engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy()
@@ -45,8 +46,9 @@ CASES = {
     "normalize_by_map (flat field, with std)": (lambda: engine.normalize_by_map(v, sd, flat, flat_std, m, s), E * 41),
     "hot_pixel_filter u8 (dark map, 3x3 median)": (lambda: engine.hot_pixel_filter(dn, dark, 0.05, 3), E * 3),
     "roi_mean u8 (flat ROI 20 %)": (lambda: engine.roi_mean(flat, x0, x1, y0, y1), (x1 - x0) * (y1 - y0) * 3),
-    "channel_statistics weighted (2 passes)": (lambda: engine.channel_statistics(v, sd), E * 32),
-    "pair_statistics weighted (2 passes, fused)": (lambda: engine.pair_statistics(v, sd, v2, sd, 0.5), E * 64),
+    "channel_statistics weighted (one pass)": (lambda: engine.channel_statistics(v, sd), E * 16),
+    "channel_statistics unweighted (one pass)": (lambda: engine.channel_statistics(v, None), E * 8),
+    "pair_statistics weighted (one pass, fused)": (lambda: engine.pair_statistics(v, sd, v2, sd, 0.5), E * 32),
     "compute_difference with std": (lambda: engine.compute_difference(v, sd, v2, sd, 0.5), E * 64),
 }
 

@@ -3,7 +3,10 @@
 per-kernel time from --kernel-trace --stats, PMC counters per launch of the merge kernel, and the HBM
 traffic corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and on gfx950
 reads exactly 1/2 of a wide coalesced streaming read's bytes -> doubled; WRITE_SIZE in KiB, exact).
-usage: summarize_profile.py <prof dir> <tag> [kernel substring] [algorithmic bytes]"""
+usage: summarize_profile.py <prof dir> <tag> [kernel substring] [algorithmic bytes] [workload] [commit]
+With a workload name it also records the measured HBM bytes per launch in profiles/r02_pmc_traffic.json (what bench.py
+prints as roofline.traffic, with the commit the counters were collected on).
+DATA-DEPENDENT KERNELS: pass the dominant kernel's name substring; counters are averaged over its launches only."""
 import csv
 import glob
 import json
@@ -11,7 +14,7 @@ import statistics
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-kname = sys.argv[3] if len(sys.argv) > 3 else "merge_u8_fast"
+kname = sys.argv[3] if len(sys.argv) > 3 else "merge_u8_val3"
 alg = int(sys.argv[4]) if len(sys.argv) > 4 else 754974720
 csv.field_size_limit(1 << 30)
 out = {"source": src}
@@ -74,4 +77,11 @@ with open(f"profiles/{tag}_rocprof_summary.md", "w") as f:
                 f"= {t['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch = {t['ratio_to_algorithmic']:.3f} x algorithmic ({alg / 1e6:.1f} MB)\n")
     if d:
         f.write("\n## Derived\n\n" + "\n".join(f"- {k}: {v:.4g}" for k, v in d.items()) + "\n")
+if len(sys.argv) > 5 and "traffic" in out:
+    import pathlib
+    tp = pathlib.Path("profiles/r02_pmc_traffic.json")
+    rec = json.load(open(tp)) if tp.exists() else {}
+    rec[sys.argv[5]] = {"hbm_bytes_per_launch": out["traffic"]["hbm_bytes_per_launch"], "ratio_to_algorithmic": out["traffic"]["ratio_to_algorithmic"],
+                        "kernel": merge["name"], "commit": sys.argv[6] if len(sys.argv) > 6 else "?", "source": f"profiles/{tag}_rocprof_summary.json"}
+    json.dump(rec, open(tp, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("merge_kernel", "launch", "counters_per_launch", "traffic", "derived", "roofline") if k in out}, indent=1))
