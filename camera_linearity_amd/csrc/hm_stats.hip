@@ -289,27 +289,46 @@ __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ 
 // by process_linearity :443-446) without materialising the two difference images and in one pass: x, y (and their stds) are read
 // once and both the absolute and the relative difference are reduced. out: 6*C doubles
 // [abs mean | abs std | abs error | rel mean | rel std | rel error].
-// difference terms of one element (measurand.py:634-653) and the statistics weights 1 / std of both differences. One division
+// 1 / sqrt(q) and 1 / x to within ~1 ulp without the IEEE expansions: the hardware estimate (v_rsq_f64 / v_rcp_f64, about 26 bits)
+// and two Newton steps - 8 / 5 instructions instead of ~26 (sqrt + divide) / 11. q = 0 gives +inf like 1 / sqrt(0).
+__device__ __forceinline__ double rsqrt_nr(double q) {
+    double y = __builtin_amdgcn_rsq(q);
+    const double h = 0.5 * q;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    if (!(q > 0.0 && q < __builtin_huge_val())) y = 1.0 / sqrt(q);      // 0 (-> inf), infinities, NaN, negatives: the IEEE results
+    return y;
+}
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    const double ax = fabs(x);
+    if (!(ax > 0.0 && ax < __builtin_huge_val())) r = 1.0 / x;          // 0, infinities, NaN: the IEEE results (x / 0 = inf as in NumPy)
+    return r;
+}
+
+// difference terms of one element (measurand.py:634-653) and the statistics weights 1 / std of both differences. One reciprocal
 // (1 / scale) and two reciprocal square roots per element: x / (m y) = x r, (ys x) / (m y^2) = ys x m r^2 with r = 1 / (m y), and
-// w = 1 / sqrt(q), std = q w - a few ulp from the reference's three divisions, two square roots and two reciprocals, which is what
-// made the all-pairs kernel FP64-VALU bound; the statistics agree with the oracle to 1e-12.
+// w = 1 / sqrt(q), std = q w - a few ulp from the reference's three divisions, two square roots and two reciprocals (the pair
+// kernels are FP64-VALU bound: 360 us for 1.6 GB on one pair); the statistics agree with the oracle to 1e-12.
 __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, double ys, double mult, bool with_std,
                                            double& a, double& as, double& wa, double& r, double& rs, double& wr) {
     const double scale = mult * yv;                     // measurand.py:634
     a = xv - scale;                                     // :635
-    const double inv = 1.0 / scale;
+    const double inv = rcp_nr(scale);
     r = a * inv;                                        // :636
     wa = 1.0; wr = 1.0;
     if (with_std) {
         const double m1 = mult * ys;
         const double qa = xs * xs + m1 * m1;            // :652
-        wa = 1.0 / sqrt(qa);
-        as = qa * wa;
+        wa = rsqrt_nr(qa);
+        as = qa > 0.0 && qa < __builtin_huge_val() ? qa * wa : sqrt(qa);
         const double u1 = xs * inv;
         const double u2 = ((ys * xv) * mult) * (inv * inv);
         const double qr = u1 * u1 + u2 * u2;            // :653
-        wr = 1.0 / sqrt(qr);
-        rs = qr * wr;
+        wr = rsqrt_nr(qr);
+        rs = qr > 0.0 && qr < __builtin_huge_val() ? qr * wr : sqrt(qr);
     }
 }
 

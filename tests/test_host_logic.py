@@ -215,3 +215,75 @@ def test_oracle_is_test_infrastructure_only():
     for name in ("bench.py", "__graft_entry__.py"):
         src = (root / name).read_text()
         assert not re.search(r"^(from\s+oracle\b|import\s+oracle\b)", src, re.M), name
+
+
+# ---------------------------------------------------------------------------------------------- dispatch (no GPU needed)
+def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False, variant=0, align=0, darks=False):
+    """hm_merge_describe runs hm_merge's own dispatch with launching switched off: pointers only need to look aligned."""
+    import ctypes as C_
+    from camera_linearity_amd import _native as nat
+    a = nat.MergeArgs()
+    a.struct_size = C_.sizeof(nat.MergeArgs)
+    a.n_frames, a.channels, a.variant = n, C, variant
+    a.height = a.rows = a.buf_rows = H
+    a.width = W
+    base = 1 << 20
+    fr = (C_.c_void_p * n)(*[base * (i + 1) + align for i in range(n)])
+    if f64:
+        a.frames_f64 = C_.cast(fr, C_.POINTER(C_.c_void_p))
+    else:
+        a.frames_u8 = C_.cast(fr, C_.POINTER(C_.c_void_p))
+    ex = (C_.c_double * n)(*[1e-3 * 2 ** i for i in range(n)])
+    a.exposures = C_.cast(ex, C_.POINTER(C_.c_double))
+    a.icrf, a.w_lut, a.out_val = base * 40, base * 41, base * 42
+    keep = [fr, ex]
+    if std:
+        sd = (C_.c_void_p * n)(*[base * (50 + i) for i in range(n)])
+        a.stds = C_.cast(sd, C_.POINTER(C_.c_void_p))
+        a.icrf_diff, a.dw_lut, a.out_std = base * 43, base * 44, base * 45
+        keep.append(sd)
+    if flat:
+        a.flat_u8 = base * 46
+        a.flat_std = base * 47
+    if sumw:
+        a.out_sum_w = base * 48
+    if darks:
+        dk = (C_.c_void_p * n)(*[base * 90 for _ in range(n)])
+        dm = (C_.c_int32 * n)(*[13] * n)
+        a.darks_u8 = C_.cast(dk, C_.POINTER(C_.c_void_p))
+        a.dark_min_dn = C_.cast(dm, C_.POINTER(C_.c_int32))
+        a.median_k = 3
+        keep += [dk, dm]
+    buf = C_.create_string_buffer(512)
+    rc = nat.lib.hm_merge_describe(C_.byref(a), buf, 512)
+    return rc, buf.value.decode()
+
+
+def test_merge_dispatch_table():
+    """Which kernel hm_merge launches for which arguments (the library's own dispatch, dry): the val-only bench shape goes to
+    merge_u8_val3 with the per-N configuration, std / flat / sum-of-weights to merge_u8_fast(_std), N > 16 and C != 3 to the
+    run-time-N kernels, float64 frames to merge_f64_*, unaligned frames to merge_generic, dark maps add the fix-up pass."""
+    from camera_linearity_amd import _native as nat
+    assert _describe(7) == (0, "merge_u8_val3<N=7,U=2,PF=1,MAP=0>")
+    assert _describe(8)[1] == "merge_u8_val3<N=8,U=2,PF=1,MAP=0>"
+    assert _describe(15)[1] == "merge_u8_val3<N=15,U=3,PF=0,MAP=0>"
+    assert _describe(7, H=4, W=8)[1] == "merge_generic<f64in=0,std=0>"                      # 96 elements: less than one group
+    assert _describe(7, H=5, W=64)[1] == "merge_u8_val3<N=7,U=2,PF=1,MAP=0> + merge_generic<f64in=0,std=0>"   # 960 = 3 groups + tail
+    assert _describe(7, std=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0>"
+    assert _describe(7, std=True, flat=True, darks=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=1,sum_w=0> + merge_fixup_hot<f64in=0,std=1>"
+    assert _describe(7, sumw=True)[1] == "merge_u8_fast<N=7,U=2,flat=0,sum_w=1>"
+    assert _describe(17)[1] == "merge_u8_loop<C=3,flat=0,sum_w=0>(N=17)"
+    assert _describe(7, C=1)[1] == "merge_u8_loop<C=1,flat=0,sum_w=0>(N=7)"
+    assert _describe(7, f64=True, std=True)[1] == "merge_f64_std<C=3,flat=0,sum_w=0>(N=7)"
+    assert _describe(7, align=1)[1] == "merge_generic<f64in=0,std=0>"
+    assert _describe(7, variant=-1)[1] == "merge_generic<f64in=0,std=0>"
+    assert _describe(7, variant=1120)[1] == "merge_u8_fast<N=7,U=2,flat=0,sum_w=0>"        # round 1's kernel stays reachable for A/B runs
+    assert _describe(33)[0] == nat.HM_EUNSUPPORTED
+
+
+def test_probe_and_tuning_variants_are_rejected_by_the_default_library():
+    """The shipped library is built without the tuning matrix: the table-free traffic probe (variant 5120: wrong results by design)
+    and the A/B variants of merge_u8_val3 / merge_u8_priv must come back as HM_EINVAL, not run."""
+    from camera_linearity_amd import _native as nat
+    for v in (5120, 5020, 7300, 7211, 8200, 8410, 999999):
+        assert _describe(7, variant=v)[0] == nat.HM_EINVAL, v
