@@ -107,51 +107,59 @@ struct Mom {
 constexpr int kMomVals = 6;
 __device__ __forceinline__ Mom mom_zero() { return Mom{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
 
-// Per-thread accumulation: blocks of kMomBlock elements are summed as shifted moments about K = the state's current mean
-// (S0 = sum w, S1 = sum w (v - K), S2 = sum w (v - K)^2: three FMAs per element, no division) and then folded into the running
-// (W, mean, M2) with Chan's formula - two divisions per block instead of two per element (the all-pairs kernel is FP64-VALU
-// bound). K tracks the data (the first block is centred on its first element), so S2 - S1^2 / S0 differences nothing large.
+// Per-thread accumulation, branch-free: kMomBlock elements are summed as shifted moments about K = the state's current mean
+// (S0 = sum w, S1 = sum w (v - K), S2 = sum w (v - K)^2: three FMAs per element, no division), an element that NumPy's nan-functions
+// would skip enters with weight 0 and deviation 0 (selects, no branch), and the block is folded into the running (W, mean, M2) with
+// Chan's formula when the LOOP COUNTER says so (wave-uniform) - two divisions per block instead of two per element. K tracks the data
+// (until the first fold it is the first valid element), so S2 - S1^2 / S0 differences nothing large.
 constexpr int kMomBlock = 8;
 struct MomAcc {
     Mom m;
     double K, S0, S1, S2;
-    int nb;
+    bool haveK;
 };
-__device__ __forceinline__ MomAcc acc_zero() { return MomAcc{mom_zero(), 0.0, 0.0, 0.0, 0.0, 0}; }
+__device__ __forceinline__ MomAcc acc_zero() { return MomAcc{mom_zero(), 0.0, 0.0, 0.0, 0.0, false}; }
 
 __device__ __forceinline__ void acc_fold(MomAcc& a) {
-    if (a.nb == 0) return;
-    const double q = a.S1 / a.S0;                                   // block mean - K
-    const double mb = a.K + q;
-    const double M2b = a.S2 - a.S1 * q;
-    if (a.m.W == 0.0) { a.m.W = a.S0; a.m.mean = mb; a.m.M2 = M2b; }
-    else {
-        const double W = a.m.W + a.S0;
-        const double d = mb - a.m.mean;
-        const double f = a.S0 / W;
-        a.m.mean = a.m.mean + d * f;
-        a.m.M2 = (a.m.M2 + M2b) + (d * d) * (a.m.W * f);
-        a.m.W = W;
+    if (a.S0 != 0.0) {                                              // (a lane whose whole block was skipped: rare, and the only branch)
+        const double q = a.S1 / a.S0;                               // block mean - K
+        const double mb = a.K + q;
+        const double M2b = a.S2 - a.S1 * q;
+        if (a.m.W == 0.0) { a.m.W = a.S0; a.m.mean = mb; a.m.M2 = M2b; }
+        else {
+            const double W = a.m.W + a.S0;
+            const double d = mb - a.m.mean;
+            const double f = a.S0 / W;
+            a.m.mean = a.m.mean + d * f;
+            a.m.M2 = (a.m.M2 + M2b) + (d * d) * (a.m.W * f);
+            a.m.W = W;
+        }
+        a.K = a.m.mean;
     }
-    a.K = a.m.mean; a.S0 = 0.0; a.S1 = 0.0; a.S2 = 0.0; a.nb = 0;
+    a.S0 = 0.0; a.S1 = 0.0; a.S2 = 0.0;
 }
 
-// one element (value v, weight w already formed, std s for the `error` sum) into the accumulator
-__device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s, bool weighted) {
+// one element: value v, weight w (already formed; 1 when unweighted), std s for the `error` sum; in_range = the element exists (tail lanes)
+__device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s, bool weighted, bool in_range) {
+    bool use;
     if (weighted) {
-        if (w == w) a.m.Wall += w;                                          // nansum(weights)
-        if (s == s) { a.m.ss += s; a.m.cs += 1.0; }                         // nanmean(stds)
+        const bool okw = in_range && (w == w);
+        const bool oks = in_range && (s == s);
+        a.m.Wall += okw ? w : 0.0;                                          // nansum(weights)
+        a.m.ss += oks ? s : 0.0;                                            // nanmean(stds)
+        a.m.cs += oks ? 1.0 : 0.0;
         const double vw = v * w;
-        if (!(vw == vw)) return;                                            // nansum(values * weights), nansum(weights * (values - mean)**2)
+        use = in_range && (vw == vw);                                       // nansum(values * weights), nansum(weights * (values - mean)**2)
     } else {
-        if (!(v == v)) return;
+        use = in_range && (v == v);
         w = 1.0;
     }
-    if (a.nb == 0 && a.m.W == 0.0) a.K = v;
-    const double d = v - a.K;
-    const double t = w * d;
-    a.S0 += w; a.S1 += t; a.S2 = fma(t, d, a.S2);
-    if (++a.nb == kMomBlock) acc_fold(a);
+    a.K = (!a.haveK && use) ? v : a.K;
+    a.haveK = a.haveK || use;
+    const double we = use ? w : 0.0;
+    const double d = use ? v - a.K : 0.0;
+    const double t = we * d;
+    a.S0 += we; a.S1 += t; a.S2 = fma(t, d, a.S2);
 }
 
 __device__ __forceinline__ Mom acc_finish(MomAcc& a, bool weighted) {
@@ -254,19 +262,21 @@ __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, c
     const bool weighted = sd != nullptr;
     constexpr int UN = 4;                                   // independent loads in flight per lane
     MomAcc st = acc_zero();
-    for (int64_t e = first; e < n; e += UN * stride) {
+    int it = 0;
+    for (int64_t e = first; e < n; e += UN * stride, ++it) {
         double vv[UN], sv[UN];
         bool ok[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int64_t q = e + u * stride;
             ok[u] = q < n;
-            vv[u] = ok[u] ? __builtin_nontemporal_load(val + q) : 0.0;
-            sv[u] = (ok[u] && sd) ? __builtin_nontemporal_load(sd + q) : 0.0;
+            const int64_t qc = ok[u] ? q : e;                                 // tail: reload element e with weight 0 instead of branching
+            vv[u] = __builtin_nontemporal_load(val + qc);
+            sv[u] = sd ? __builtin_nontemporal_load(sd + qc) : 1.0;
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
-            if (ok[u]) acc_add(st, vv[u], weighted ? 1.0 / sv[u] : 1.0, sv[u], weighted);                 // w = 1 / std, :342
+        for (int u = 0; u < UN; ++u) acc_add(st, vv[u], weighted ? 1.0 / sv[u] : 1.0, sv[u], weighted, ok[u]);    // w = 1 / std, :342
+        if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) acc_fold(st);
     }
     const Mom mine[1] = {acc_finish(st, weighted)};
     block_merge_store<1>(mine, ct, partial);
@@ -289,23 +299,24 @@ __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ 
 // by process_linearity :443-446) without materialising the two difference images and in one pass: x, y (and their stds) are read
 // once and both the absolute and the relative difference are reduced. out: 6*C doubles
 // [abs mean | abs std | abs error | rel mean | rel std | rel error].
-// 1 / sqrt(q) and 1 / x to within ~1 ulp without the IEEE expansions: the hardware estimate (v_rsq_f64 / v_rcp_f64, about 26 bits)
-// and two Newton steps - 8 / 5 instructions instead of ~26 (sqrt + divide) / 11. q = 0 gives +inf like 1 / sqrt(0).
-__device__ __forceinline__ double rsqrt_nr(double q) {
-    double y = __builtin_amdgcn_rsq(q);
-    const double h = 0.5 * q;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    if (!(q > 0.0 && q < __builtin_huge_val())) y = 1.0 / sqrt(q);      // 0 (-> inf), infinities, NaN, negatives: the IEEE results
-    return y;
-}
+// 1 / x and 1 / sqrt(q) to within ~1 ulp without the IEEE expansions and without branches: the hardware estimate (v_rcp_f64 /
+// v_rsq_f64, about 26 bits; already the IEEE answer for 0, infinities and NaN) and two Newton steps, kept only when the estimate is a
+// finite non-zero number - 7 / 10 instructions instead of 11 (divide) / ~26 (sqrt + divide).
+__device__ __forceinline__ bool finite_nonzero(double x) { const double ax = fabs(x); return ax > 0.0 && ax < __builtin_huge_val(); }
 __device__ __forceinline__ double rcp_nr(double x) {
-    double r = __builtin_amdgcn_rcp(x);
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double r = fma(fma(-x, r0, 1.0), r0, r0);
     r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    const double ax = fabs(x);
-    if (!(ax > 0.0 && ax < __builtin_huge_val())) r = 1.0 / x;          // 0, infinities, NaN: the IEEE results (x / 0 = inf as in NumPy)
-    return r;
+    return finite_nonzero(r0) ? r : r0;
+}
+__device__ __forceinline__ double rsqrt_nr(double q, double& root) {       // also sqrt(q) = q * rsqrt(q)
+    const double y0 = __builtin_amdgcn_rsq(q);
+    const double h = 0.5 * q;
+    double y = y0 * fma(-h * y0, y0, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    const bool ok = finite_nonzero(y0);
+    root = ok ? q * y : q;                                                   // sqrt(0) = 0, sqrt(inf) = inf, NaN stays NaN (q is a sum of squares)
+    return ok ? y : y0;
 }
 
 // difference terms of one element (measurand.py:634-653) and the statistics weights 1 / std of both differences. One reciprocal
@@ -322,13 +333,11 @@ __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, doub
     if (with_std) {
         const double m1 = mult * ys;
         const double qa = xs * xs + m1 * m1;            // :652
-        wa = rsqrt_nr(qa);
-        as = qa > 0.0 && qa < __builtin_huge_val() ? qa * wa : sqrt(qa);
+        wa = rsqrt_nr(qa, as);
         const double u1 = xs * inv;
         const double u2 = ((ys * xv) * mult) * (inv * inv);
         const double qr = u1 * u1 + u2 * u2;            // :653
-        wr = rsqrt_nr(qr);
-        rs = qr > 0.0 && qr < __builtin_huge_val() ? qr * wr : sqrt(qr);
+        wr = rsqrt_nr(qr, rs);
     }
 }
 
@@ -341,26 +350,28 @@ __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x
     const int ct = static_cast<int>(first % C);
     MomAcc st[2] = {acc_zero(), acc_zero()};                                   // absolute | relative difference
     constexpr int UN = 2;
-    for (int64_t e0 = first; e0 < n; e0 += UN * stride) {
+    int it = 0;
+    for (int64_t e0 = first; e0 < n; e0 += UN * stride, ++it) {
         double xv[UN], yv[UN], xs[UN], ys[UN];
         bool ok[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int64_t q = e0 + u * stride;
             ok[u] = q < n;
-            xv[u] = ok[u] ? __builtin_nontemporal_load(x + q) : 0.0;
-            yv[u] = ok[u] ? __builtin_nontemporal_load(y + q) : 1.0;
-            xs[u] = (ok[u] && sx) ? __builtin_nontemporal_load(sx + q) : 0.0;
-            ys[u] = (ok[u] && sy) ? __builtin_nontemporal_load(sy + q) : 0.0;
+            const int64_t qc = ok[u] ? q : e0;                                  // tail: a valid address, weight 0
+            xv[u] = __builtin_nontemporal_load(x + qc);
+            yv[u] = __builtin_nontemporal_load(y + qc);
+            xs[u] = sx ? __builtin_nontemporal_load(sx + qc) : 0.0;
+            ys[u] = sy ? __builtin_nontemporal_load(sy + qc) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            if (!ok[u]) continue;
             double a, as = 0.0, wa, r, rs = 0.0, wr;
             pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, a, as, wa, r, rs, wr);
-            acc_add(st[0], a, wa, as, with_std);
-            acc_add(st[1], r, wr, rs, with_std);
+            acc_add(st[0], a, wa, as, with_std, ok[u]);
+            acc_add(st[1], r, wr, rs, with_std, ok[u]);
         }
+        if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold(st[0]); acc_fold(st[1]); }
     }
     const Mom mine[2] = {acc_finish(st[0], with_std), acc_finish(st[1], with_std)};
     block_merge_store<2>(mine, ct, partial);
@@ -410,26 +421,28 @@ __global__ __launch_bounds__(1024) void k_pairs_stats(const PairsK a, double* __
     const int ct = static_cast<int>(first % a.C);
     MomAcc st[2] = {acc_zero(), acc_zero()};                                                   // absolute | relative difference
     constexpr int UN = 2;
-    for (int64_t e0 = first; e0 < a.n; e0 += UN * stride) {
+    int it = 0;
+    for (int64_t e0 = first; e0 < a.n; e0 += UN * stride, ++it) {
         double xv[UN], yv[UN], xs[UN], ys[UN];
         bool ok[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int64_t q = e0 + u * stride;
             ok[u] = q < a.n;
-            xv[u] = ok[u] ? x[q] : 0.0;                                                        // (default cache policy: the other waves re-read these lines)
-            yv[u] = ok[u] ? y[q] : 1.0;
-            xs[u] = (ok[u] && sx) ? sx[q] : 0.0;
-            ys[u] = (ok[u] && sy) ? sy[q] : 0.0;
+            const int64_t qc = ok[u] ? q : e0;                                                 // tail: a valid address, weight 0
+            xv[u] = x[qc];                                                                     // (default cache policy: the other waves re-read these lines)
+            yv[u] = y[qc];
+            xs[u] = sx ? sx[qc] : 0.0;
+            ys[u] = sy ? sy[qc] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            if (!ok[u]) continue;
             double av, as = 0.0, wa, rv, rs = 0.0, wr;
             pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, av, as, wa, rv, rs, wr);
-            acc_add(st[0], av, wa, as, with_std);
-            acc_add(st[1], rv, wr, rs, with_std);
+            acc_add(st[0], av, wa, as, with_std, ok[u]);
+            acc_add(st[1], rv, wr, rs, with_std, ok[u]);
         }
+        if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold(st[0]); acc_fold(st[1]); }
     }
     const Mom mine[2] = {acc_finish(st[0], with_std), acc_finish(st[1], with_std)};
 #pragma unroll
