@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void k_linearize(const void* __restrict__ in, 
 // lane constant), lane l handles elements 2l, 2l + 1 of a sub-unit - one ushort (uint8 input) or one 16-byte (float64 input) load
 // per sub-unit and 16-byte stores that make every store instruction a contiguous 1 KB; the NEXT group's loads are issued before
 // the current group's gathers. The general kernel below issues one load per lane and loop iteration and waits for it: a wave then
-// spends its life in HBM round trips (0.55-0.60 of the roofline where the table-free hm_u8_to_unit_f64 gets 0.79 on the same
-// traffic). Takes C == 3 with a per-channel table, or any C with a single table (lut_stride == 1), on aligned buffers; hm_linearize_*
-// sends the body here and the tail (n mod 384) and everything else to k_linearize.
+// spends more of its life in HBM round trips when there are several input streams (float64 values, float64 std). Takes C == 3 with a
+// per-channel table, or any C with a single table (lut_stride == 1), on aligned buffers; hm_linearize_* sends the body here where this
+// kernel is the faster one (measured: see linearize_common) and the tail (n mod 384) and everything else to k_linearize.
 constexpr uint32_t kLinSub = 128, kLinU = 3, kLinGroup = kLinSub * kLinU;
 
 template <bool F64IN, bool STD, bool PERCH>
@@ -276,7 +276,11 @@ static int linearize_common(bool f64in, const void* in, const double* sd, const 
     const bool shape_ok = (perch && C == 3) || !perch;
     const bool align_ok = aligned(out_val, 16) && (!with_std || (aligned(sd, 16) && aligned(out_std, 16))) &&
                           (f64in ? aligned(in, 16) : aligned(in, 2)) && (!out_idx || aligned(out_idx, 2));
-    if (shape_ok && align_ok && n / kLinGroup > 0 && n / kLinGroup < (int64_t{1} << 31)) {
+    // ... and when it is the faster of the two (tools/lin_ab.py, one box, tables resident): float64 input 131 vs 144 us, + std 272 vs 307 us,
+    // uint8 + std 220 vs 239 us - but uint8 WITHOUT std (9 B/element, 8 of them written) 95 vs 69 us: that case stays on the general kernel,
+    // whose plain thread-strided loop (1 KB per wave and step over a window of 8 MB) reaches 0.81 of the roofline, like hm_u8_to_unit_f64.
+    const bool stream_wins = f64in || with_std;
+    if (stream_wins && shape_ok && align_ok && n / kLinGroup > 0 && n / kLinGroup < (int64_t{1} << 31)) {
         const uint32_t groups = static_cast<uint32_t>(n / kLinGroup);
         body = static_cast<int64_t>(groups) * kLinGroup;
         const unsigned sgrid = stream_grid(groups, 4, 8);
