@@ -321,6 +321,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N > 1 path on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even at world size 1")
+    ap.add_argument("--hot-density", type=float, default=1e-4, help="fraction of hot elements in the synthetic dark maps (cfg3 / cfg3hot)")
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the stack the CPU baseline merges (0 = per workload: 4096 val-only, 512 with std / corrections)")
     a = ap.parse_args()
@@ -376,7 +377,7 @@ def main():
         kw = {}
         extra = {}
         if corr:
-            flat, flat_std, dark = synthetic_flat_dark(seed, H, W, device=dev)
+            flat, flat_std, dark = synthetic_flat_dark(seed, H, W, device=dev, hot_density=a.hot_density)
             extra.update(flat=flat, flat_std=flat_std, dark=dark)
             x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
             if corr in (True, "flat"):
@@ -489,6 +490,7 @@ def main():
                                    + " -> float64 radiance" + (" + uncertainty" if with_std else "")
                                    + (f"; {len(plans)} distinct resident stacks merged round-robin (cold inputs)" if len(plans) > 1 and launches_per_step == 1 else ""),
                        "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3, "resident_stacks": len(plans),
+                       "hot_density": a.hot_density if corr in (True, "hot") else None,
                        "parallelism": f"independent stacks x{world * max(launches_per_step, 1)} per step, no collective", "variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
