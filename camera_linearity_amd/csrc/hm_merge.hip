@@ -1903,6 +1903,32 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
         const int64_t need_hi = g->row0 + g->rows + r > g->height ? g->height : g->row0 + g->rows + r;
         if (g->buf_row0 > need_lo || g->buf_row0 + g->buf_rows < need_hi) return HM_ESHAPE;   // halo too small
     }
+    // The streaming kernels index groups and buffer offsets with 32 bits: a tile of 2^32 elements or more is merged as consecutive
+    // row bands of fewer than 2^32 elements each (same buffers, row0 / rows / output pointers advanced; an even number of rows per band
+    // keeps every band's first byte 2-byte aligned). Only a single row of >= 2^32 elements is left to merge_generic.
+    {
+        const int64_t per_row = g->width * static_cast<int64_t>(C);
+        const int64_t limit = (int64_t{1} << 32) - 1;
+        if (g->rows * per_row > limit && per_row <= limit / 2 && g->variant >= 0) {
+            int64_t band_rows = limit / per_row;
+            if (band_rows > 1) band_rows &= ~int64_t{1};
+            for (int64_t r = 0; r < g->rows; r += band_rows) {
+                hm_merge_args b = *g;
+                b.row0 = g->row0 + r;
+                b.rows = g->rows - r < band_rows ? g->rows - r : band_rows;
+                const int64_t adv = r * per_row;                       // outputs and the flat field cover the OUTPUT rows
+                if (g->out_val) b.out_val = g->out_val + adv;
+                if (g->out_std) b.out_std = g->out_std + adv;
+                if (g->out_sum_w) b.out_sum_w = g->out_sum_w + adv;
+                if (g->flat_u8) b.flat_u8 = g->flat_u8 + adv;
+                if (g->flat_f64) b.flat_f64 = g->flat_f64 + adv;
+                if (g->flat_std) b.flat_std = g->flat_std + adv;
+                const int rc_b = hm_merge(&b, stream);
+                if (rc_b != HM_OK) return rc_b;
+            }
+            return HM_OK;
+        }
+    }
     MergeK k{};
     for (int i = 0; i < N; ++i) {
         const void* f = f64in ? static_cast<const void*>(g->frames_f64[i]) : static_cast<const void*>(g->frames_u8[i]);

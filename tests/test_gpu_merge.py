@@ -743,3 +743,32 @@ def test_config4_row_tile_shape(eng, with_std):
     close(host(tile.outputs["val"][:rows]), ref["val"][1:rows + 1], VAL_RTOL)
     if with_std:
         close(host(tile.outputs["std"][:rows]), ref["std"][1:rows + 1], STD_RTOL)
+
+
+def test_merge_tile_of_more_than_2_pow_32_elements(eng):
+    """Maximum sizes: a tile of 65538 x 21846 x 3 = 4 295 229 444 elements (> 2^32; 4.3 GB per uint8 frame, 34 GB of float64 output).
+    hm_merge splits it into row bands for the 32-bit-indexed streaming kernels: the result must equal, bit for bit, the same rows merged as
+    explicit tiles by the caller, and the rows either side of the internal band boundary must match the oracle."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * (1 << 30):
+        pytest.skip("needs ~80 GB of free HBM")
+    from camera_linearity_amd.synthetic import synthetic_icrf
+    H, W, n = 65538, 21846, 2
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    frames = [torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(n)]
+    t = [1e-3, 4e-3]
+    icrf, _ = synthetic_icrf()
+    plan = eng.plan_merge(frames, t, icrf)
+    assert plan.kernels.count("merge_u8_val3<N=2") == 2                      # two row bands, both through the streaming kernel
+    plan.launch()
+    whole = plan.outputs["val"]
+    cut = 30000
+    top = eng.merge([f[:cut] for f in frames], t, icrf, height=H, row0=0, rows=cut, buf_row0=0)["val"]
+    assert torch.equal(top, whole[:cut])
+    del top
+    bot = eng.merge([f[cut:] for f in frames], t, icrf, height=H, row0=cut, rows=H - cut, buf_row0=cut)["val"]
+    assert torch.equal(bot, whole[cut:])
+    del bot
+    r0 = 65530                                                               # the internal boundary is at row 65534
+    ref = orc.merge([f[r0:].cpu().numpy() for f in frames], t, icrf)
+    close(host(whole[r0:]), ref["val"], VAL_RTOL)

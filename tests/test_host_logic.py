@@ -287,3 +287,15 @@ def test_probe_and_tuning_variants_are_rejected_by_the_default_library():
     from camera_linearity_amd import _native as nat
     for v in (5120, 5020, 7300, 7211, 8200, 8410, 999999):
         assert _describe(7, variant=v)[0] == nat.HM_EINVAL, v
+
+
+def test_merge_splits_huge_tiles_into_row_bands():
+    """A tile of 2^32 elements or more (the streaming kernels index with 32 bits) is dispatched as row bands, each through the
+    streaming kernel - not handed to merge_generic as in round 1."""
+    rc, names = _describe(7, H=65538, W=21846)                     # 65538 * 65538 = 4 295 229 444 elements > 2^32
+    assert rc == 0
+    parts = names.split(" + ")
+    assert parts[0] == "merge_u8_val3<N=7,U=2,PF=1,MAP=0>" and parts.count("merge_u8_val3<N=7,U=2,PF=1,MAP=0>") == 2, names
+    assert all(p.startswith("merge_u8_val3") or p.startswith("merge_generic") for p in parts)
+    rc, names = _describe(7, H=65538, W=21846, std=True, darks=True)
+    assert rc == 0 and names.count("merge_u8_fast_std") == 2 and names.count("merge_fixup_hot") == 2
