@@ -8,6 +8,10 @@
 
 namespace hm {
 
+#ifndef HM_HOT_UN
+#define HM_HOT_UN 2      // batches of loads in flight per lane: 1 -> 0.56, 2 -> 0.60, 6 (a wave's whole share of a 4096 x 4096 x 3 frame at once, 137 VGPRs) -> 0.49
+#endif
+
 // Streaming copy with the rare hot elements patched: every lane owns EL consecutive elements (16 bytes of x:
 // 16 uint8 or 2 float64), loads them and the matching map entries with vector loads, and a wave ballot finds the
 // lanes that hold hot elements; each hot element's k x k median is taken cooperatively by the whole wave
@@ -30,11 +34,11 @@ __global__ __launch_bounds__(256) void k_hot_filter(const T* __restrict__ x, con
     const int64_t n_waves = (static_cast<int64_t>(gridDim.x) * blockDim.x) >> 6;
     const bool vec_x = aligned_dev(x, 16) && aligned_dev(out, 16);
     // UN batches of 64 chunks per iteration: the 16-byte loads of x and of the map for all of them are issued before the first
-    // ballot (one batch per iteration left a single pair of loads in flight per lane: 0.56 of the roofline, r01e_bench_ops.json)
-    constexpr int UN = 2;
+    // ballot (one batch per iteration left a single pair of loads in flight per lane: 0.56 of the roofline, r01e_bench_ops.json).
+    constexpr int UN = HM_HOT_UN;
     const int64_t wstride = n_waves * 64;
     for (int64_t cb0 = wave0 * 64; cb0 < n_chunks; cb0 += UN * wstride) {       // wave-uniform trip count
-        T v[UN][EL];
+        cu32x4 xr[UN];                                                           // the lane's 16 bytes of x per batch, kept packed
         uint32_t hotbits[UN];
         int cnts[UN];
 #pragma unroll
@@ -44,11 +48,13 @@ __global__ __launch_bounds__(256) void k_hot_filter(const T* __restrict__ x, con
             const int cnt = chunk < n_chunks ? static_cast<int>(n - e0 < EL ? n - e0 : EL) : 0;
             cnts[q] = cnt;
             hotbits[q] = 0;
+            xr[q] = cu32x4{0u, 0u, 0u, 0u};
             if (cnt == EL && vec_x) {
-                const cu32x4 r = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(x + e0));
-                __builtin_memcpy(v[q], &r, 16);
-            } else {
-                for (int j = 0; j < cnt; ++j) v[q][j] = x[e0 + j];
+                xr[q] = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(x + e0));
+            } else if (cnt > 0) {
+                T tmp[EL] = {};
+                for (int j = 0; j < cnt; ++j) tmp[j] = x[e0 + j];
+                __builtin_memcpy(&xr[q], tmp, 16);
             }
             if (map_u8 && cnt == EL && EL == 16 && aligned_dev(map_u8 + e0, 16)) {
                 const cu32x4 mr = __builtin_nontemporal_load(reinterpret_cast<const cu32x4*>(map_u8 + e0));
@@ -79,19 +85,22 @@ __global__ __launch_bounds__(256) void k_hot_filter(const T* __restrict__ x, con
                     const int64_t wc = W * C;
                     const int64_t row = e / wc, rem = e % wc;
                     const T med = wave_median(x, H, W, C, 0, row, rem / C, static_cast<int>(rem % C), k);
-                    if (lane == src) {
+                    if (lane == src) {                                               // patch element j of the packed 16 bytes
+                        T tmp[EL];
+                        __builtin_memcpy(tmp, &xr[q], 16);
 #pragma unroll
-                        for (int p = 0; p < EL; ++p) v[q][p] = (p == j) ? med : v[q][p];
+                        for (int p = 0; p < EL; ++p) tmp[p] = (p == j) ? med : tmp[p];
+                        __builtin_memcpy(&xr[q], tmp, 16);
                     }
                 }
             }
             const int64_t e0 = (cb + lane) * EL;
             if (cnts[q] == EL && vec_x) {
-                cu32x4 r;
-                __builtin_memcpy(&r, v[q], 16);
-                __builtin_nontemporal_store(r, reinterpret_cast<cu32x4*>(out + e0));
-            } else {
-                for (int j = 0; j < cnts[q]; ++j) out[e0 + j] = v[q][j];
+                __builtin_nontemporal_store(xr[q], reinterpret_cast<cu32x4*>(out + e0));
+            } else if (cnts[q] > 0) {
+                T tmp[EL];
+                __builtin_memcpy(tmp, &xr[q], 16);
+                for (int j = 0; j < cnts[q]; ++j) out[e0 + j] = tmp[j];
             }
         }
     }
