@@ -42,3 +42,24 @@ extern "C" int hm_gaussian_weight_lut_host(double* w_lut, double* dw_lut) {
     }
     return HM_OK;
 }
+
+
+// Shader-clock probe (diagnostic): ONE wave on a side stream samples s_memtime (shader cycles) and s_memrealtime (100 MHz)
+// at its start and after `spins` sleep periods, while the caller's kernels run on another stream: out[0] = shader cycles, out[1] = 100 MHz
+// ticks, so clock [GHz] = out[0] / out[1] / 10. The values go to a buffer of their own; nothing else reads them.
+namespace hm {
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, int spins) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < spins; ++i) __builtin_amdgcn_s_sleep(127);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+}  // namespace hm
+
+extern "C" int hm_debug_clock_probe(unsigned long long* out_device /*2 x uint64*/, int spins, void* stream) {
+    if (!out_device || spins < 1) return HM_EINVAL;
+    hipLaunchKernelGGL(hm::k_clock_probe, dim3(1), dim3(64), 0, hm::as_stream(stream), out_device, spins);
+    return hm::launch_status();
+}

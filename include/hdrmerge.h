@@ -50,6 +50,9 @@ enum {
 int hm_version(void);                 /* HM_ABI_VERSION of the loaded library          */
 const char* hm_strerror(int code);    /* static string, never NULL                     */
 int hm_device_info(int* n_devices, int* cu_count, int* lds_bytes, char* arch, int arch_len);
+/* Diagnostic: one wave samples the shader-cycle counter and the 100 MHz real-time counter over `spins` sleep periods on `stream` (launch it on a
+ * side stream while the kernels of interest run): out_device[0] = shader cycles, out_device[1] = 100 MHz ticks -> clock [GHz] = [0] / [1] / 10. */
+int hm_debug_clock_probe(unsigned long long* out_device, int spins, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row 3 - AbstractMeasurand.apply_gaussian_weight (modules/measurand.py:606-618)
