@@ -132,6 +132,8 @@ class RowTileSet:
 
     def download(self):
         """{tile: (val, std | None)} as pinned host tensors; the merges must have been launched on the current stream."""
+        if not self.mine:                                   # more ranks than tiles: nothing to bring back
+            return {}
         dev = self.plans[self.mine[0]].device
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(dev)
