@@ -432,3 +432,29 @@ def test_all_pairs_fused_linearity(use_std):
                     np.testing.assert_allclose(got[key].cpu().numpy(), ref[key], rtol=1e-11)
                     np.testing.assert_allclose(got[key].cpu().numpy(), single[key].cpu().numpy(), rtol=1e-12)
     assert k == 18
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_one_pass_statistics_are_stable(weighted):
+    """The one-pass (block-shifted moments + Chan merge) statistics on data that break a naive sum-of-squares: mean 1e6, spread 1e-3
+    (relative 1e-9), a quarter of the elements NaN, and a 4096 x 1024 x 3 image so that every level of the merge tree is exercised.
+    Against NumPy's two-pass nanmean / nanstd (the reference's formulas, modules/measurand.py:339-349) in float64: std to 1e-8 relative
+    (a naive E[x^2] - E[x]^2 in float64 has NO correct digit here), mean to 1e-13 (NumPy's own pairwise sum is no better)."""
+    from camera_linearity_amd import engine
+    rng = np.random.default_rng(23)
+    shape = (4096, 1024, 3)
+    v = 1.0e6 + 1.0e-3 * rng.standard_normal(shape) + np.array([0.0, 5.0, -3.0])
+    v[rng.random(shape) < 0.25] = np.nan
+    s = None
+    if weighted:
+        s = 0.5 + rng.random(shape)
+        s[np.isnan(v)] = np.nan
+    ref = orc.dimension_statistics(v, s, (0, 1))
+    got = engine.channel_statistics(torch.as_tensor(v, device="cuda"), None if s is None else torch.as_tensor(s, device="cuda"))
+    np.testing.assert_allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=1e-13)
+    np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=1e-8)
+    if weighted:
+        np.testing.assert_allclose(got["error"].cpu().numpy(), ref["error"], rtol=1e-13)
+    # bit-reproducible: a second launch gives the same bits
+    again = engine.channel_statistics(torch.as_tensor(v, device="cuda"), None if s is None else torch.as_tensor(s, device="cuda"))
+    assert torch.equal(again["std"], got["std"]) and torch.equal(again["mean"], got["mean"])
