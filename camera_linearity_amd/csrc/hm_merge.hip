@@ -688,7 +688,11 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
                 for (int i = 0; i < NF; ++i) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+#ifdef HM_PROBE_STD   /* table-free traffic probe of the std kernels (wrong results; tuning builds only) */
+                        const double w = static_cast<double>((j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8)) + 1u);
+#else
                         const double w = t_wdw[j == 0 ? (cur[i][s] & 255u) : (cur[i][s] >> 8)].x;
+#endif
                         if (i == 0) S[j] = w; else S[j] += w;
                     }
                     if ((i & 3) == 3 && i != NF - 1) {      // at most 8 weight gathers in flight (large N: registers)
@@ -720,8 +724,13 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const uint32_t dn = j == 0 ? (packed & 255u) : (packed >> 8);
+#ifdef HM_PROBE_STD
+                        const double2 wdw = double2{static_cast<double>(dn + 1u), static_cast<double>(dn + 2u)};
+                        const double2 gd = double2{static_cast<double>(dn + coffs[j]), static_cast<double>(dn + 3u)};
+#else
                         const double2 wdw = t_wdw[dn];
                         const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
+#endif
                         const double w = wdw.x, dw = wdw.y, gg = gd.x;
                         const double dg = gd.y * (j == 0 ? sdv.x : sdv.y);                       // measurand.py:512
                         const double A = (dw * gg + w * dg) * invS[j] - ((dw * w) * gg) * invS2[j];   // :389

@@ -10,13 +10,13 @@
 
 namespace hm {
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 struct ChanLimits { double lo[HM_MAX_CHANNELS]; double hi[HM_MAX_CHANNELS]; };
 
 // In place; two elements per lane (16-byte loads; a store only where something changes - thresholds usually clip a
 // minority), running channel counter.
 __global__ __launch_bounds__(256) void k_thresholds(double* __restrict__ val, double* __restrict__ sd, const ChanLimits lim,
                                                     int64_t n, int C) {
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     const int64_t units = n / 2;
@@ -90,7 +90,12 @@ __global__ __launch_bounds__(256) void k_interpolate(const double* __restrict__ 
 // partials are combined with the same pairwise formula in a fixed tree order (bit-reproducible; as stable as the two-pass form:
 // moments are always taken about a mean of the data they cover). NaNs are skipped exactly as np.nansum / np.nanmean do, term by
 // term: `Wall` sums every non-NaN weight (the reference's denominators), the moments take the elements whose v * w is not NaN.
-constexpr int kStatBlocks = 2040;                           // a multiple of 12: total threads divisible by C = 1..4
+// workgroups of the reduction kernels: 3 per CU. A/B on one box (tools/ab_ops.sh, tools/ab_lin.sh, profiles/r02h_ab_stat_blocks.log): 2040
+// -> 768 takes channel statistics from 0.65 / 0.59 to 0.73 / 0.69 of 8 TB/s and the all-pairs kernel from 1.53 / 2.91 to 1.37 / 2.77 ms
+#ifndef HM_STAT_BLOCKS
+#define HM_STAT_BLOCKS 768
+#endif
+constexpr int kStatBlocks = HM_STAT_BLOCKS;                           // a multiple of 12: total threads divisible by C = 1..4
 
 static int stat_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
@@ -117,19 +122,24 @@ struct MomAcc {
     Mom m;
     double K, S0, S1, S2;
     bool haveK;
+    int cnt;            // acc_add_pair: count of the non-NaN stds as an integer (folded into m.cs by acc_finish)
 };
-__device__ __forceinline__ MomAcc acc_zero() { return MomAcc{mom_zero(), 0.0, 0.0, 0.0, 0.0, false}; }
+__device__ __forceinline__ MomAcc acc_zero() { return MomAcc{mom_zero(), 0.0, 0.0, 0.0, 0.0, false, 0}; }
 
+__device__ __forceinline__ double rcp_nr(double x);
+// RCP: the two quotients of a fold as products with rcp_nr() (~1 ulp; 14 instructions instead of two IEEE division expansions) - the
+// pair kernels, which are FP64-VALU bound and fold two states per 8 element-pairs
+template <bool RCP = false>
 __device__ __forceinline__ void acc_fold(MomAcc& a) {
     if (a.S0 != 0.0) {                                              // (a lane whose whole block was skipped: rare, and the only branch)
-        const double q = a.S1 / a.S0;                               // block mean - K
+        const double q = RCP ? a.S1 * rcp_nr(a.S0) : a.S1 / a.S0;   // block mean - K
         const double mb = a.K + q;
         const double M2b = a.S2 - a.S1 * q;
         if (a.m.W == 0.0) { a.m.W = a.S0; a.m.mean = mb; a.m.M2 = M2b; }
         else {
             const double W = a.m.W + a.S0;
             const double d = mb - a.m.mean;
-            const double f = a.S0 / W;
+            const double f = RCP ? a.S0 * rcp_nr(W) : a.S0 / W;
             a.m.mean = a.m.mean + d * f;
             a.m.M2 = (a.m.M2 + M2b) + (d * d) * (a.m.W * f);
             a.m.W = W;
@@ -162,10 +172,46 @@ __device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s,
     a.S0 += we; a.S1 += t; a.S2 = fma(t, d, a.S2);
 }
 
+template <bool RCP = false>
 __device__ __forceinline__ Mom acc_finish(MomAcc& a, bool weighted) {
-    acc_fold(a);
+    acc_fold<RCP>(a);
     if (!weighted) a.m.Wall = a.m.W;
+    a.m.cs += static_cast<double>(a.cnt);
     return a.m;
+}
+
+// acc_add for the pair kernels. Weighted: w = 1 / sqrt(q) >= 0 and s = sqrt(q) >= 0 are NaN together (q NaN), so max(., 0) replaces
+// the NaN selects of nansum(weights) / nansum(stds) and ONE comparison counts the non-NaN stds in an integer. Unweighted: w = 1.
+// Elements that do not exist (tail lanes) must arrive as NaNs (value, and std when weighted).
+// max(x, 0) with NaN -> 0 as ONE v_max_f64: fmax() puts a canonicalising v_max_f64 x, x in front because it cannot rule out a
+// signalling NaN; x is the result of arithmetic here, never one
+__device__ __forceinline__ double max0_nan_to_zero(double x) {
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+template <bool WEIGHTED>
+__device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, double s) {
+    bool use;
+    if constexpr (WEIGHTED) {
+        a.m.Wall += max0_nan_to_zero(w);
+        a.m.ss += max0_nan_to_zero(s);
+        a.cnt += (s == s) ? 1 : 0;
+        const double vw = v * w;
+        use = vw == vw;
+    } else {
+        use = v == v;
+    }
+    a.K = (!a.haveK && use) ? v : a.K;
+    a.haveK = a.haveK || use;
+    const double d = use ? v - a.K : 0.0;
+    if constexpr (WEIGHTED) {
+        const double we = use ? w : 0.0;
+        const double t = we * d;
+        a.S0 += we; a.S1 += t; a.S2 = fma(t, d, a.S2);
+    } else {
+        a.S0 += use ? 1.0 : 0.0; a.S1 += d; a.S2 = fma(d, d, a.S2);
+    }
 }
 
 // Chan / Golub / LeVeque pairwise combination; an empty side (W == 0) leaves the other's moments untouched
@@ -251,46 +297,111 @@ __device__ __forceinline__ void mom_finish(const Mom& m, bool weighted, double& 
     err = weighted ? m.ss / m.cs : nan;
 }
 
-// The launch uses a total thread count that is a multiple of C (grid rounded to a multiple of 12 workgroups), so a thread's
-// elements all have the same channel ct = first_element % C. Two independent running states per thread (even / odd visits)
-// keep two division chains in flight; they are combined first.
+// 8-byte load at (wave-uniform base) + (32-bit byte offset in a VGPR): one 64-bit add per load, no per-lane index arithmetic
+template <bool NT>
+__device__ __forceinline__ double ld_f64_sv(const double* sbase, uint32_t byte_off) {
+    typedef const __attribute__((address_space(1))) double* gdp;
+    typedef const __attribute__((address_space(1))) char* gcp;
+    gdp p = (gdp)((gcp)sbase + byte_off);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+// 1 / s as the IEEE division gives it, without the division's operand scaling and fix-up instructions: the estimate, two Newton
+// steps and Markstein's correction - instruction for instruction what hipcc emits for 1.0 / s minus v_div_scale_f64 (x 2) and
+// v_div_fixup_f64, which are the identity for 2^-500 <= |s| <= 2^500 (hm_merge.hip: div_inrange). `special` reports a lane outside
+// that range (zero, denormal, huge, infinite; a NaN needs no help); the caller then divides properly for the whole wave.
+__device__ __forceinline__ double recip_inrange(double s, bool& special) {
+    const double as = fabs(s);
+    special = as < 0x1p-500 || as > 0x1p500;
+    double r = __builtin_amdgcn_rcp(s);
+    double e = fma(-s, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-s, r, 1.0);
+    r = fma(r, e, r);
+    const double q = 1.0 * r;
+    const double res = fma(-s, q, 1.0);
+    return fma(res, r, q);
+}
+
+// The launch uses a total thread count that is a multiple of C (grid rounded to a multiple of 12 workgroups), so a lane's
+// elements all have the same channel ct = first_element % C. A wave walks over 64-element chunks (sb, sb + stride, ...: four per
+// iteration), whole chunks on a select-free path with the next iteration's loads issued before the current one's arithmetic (two
+// register sets, unconditional prefetch: see pair_loop), the last partial ones with their missing elements at weight 0.
+template <bool WEIGHTED>
+__device__ __forceinline__ Mom stats_loop(const double* val, const double* sd, int64_t n, int64_t sb0, int64_t stride, uint32_t lane) {
+    constexpr int UN = 4;                                   // 64-element chunks per iteration
+    MomAcc st = acc_zero();
+    const uint32_t lo = lane * 8u;
+    int it = 0;
+    int64_t sb = sb0;
+    auto add = [&](double v, double s, bool ok) {
+        double w = 1.0;
+        if constexpr (WEIGHTED) {                           // w = 1 / std, measurand.py:342
+            bool special;
+            w = recip_inrange(s, special);
+            if (__builtin_amdgcn_ballot_w64(special) != 0) w = 1.0 / s;
+        }
+        acc_add(st, v, w, s, WEIGHTED, ok);
+    };
+    auto fold = [&]() { if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) acc_fold<false>(st); };
+    auto whole = [&](int64_t b) { return b + (UN - 1) * stride + 64 <= n; };
+    auto load = [&](int64_t b, double (&vv)[UN], double (&sv)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t cb = b + u * stride;                                   // scalar
+            vv[u] = ld_f64_sv<true>(val + cb, lo);
+            sv[u] = WEIGHTED ? ld_f64_sv<true>(sd + cb, lo) : 1.0;
+        }
+    };
+    auto process = [&](const double (&vv)[UN], const double (&sv)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) add(vv[u], sv[u], true);
+        fold();
+    };
+    const int64_t step = UN * stride;
+    double va[UN], sa[UN], vb[UN], sbv[UN];
+    if (whole(sb)) load(sb, va, sa);
+    while (whole(sb)) {
+        load(whole(sb + step) ? sb + step : sb, vb, sbv);
+        process(va, sa);
+        ++it; sb += step;
+        if (!whole(sb)) break;
+        load(whole(sb + step) ? sb + step : sb, va, sa);
+        process(vb, sbv);
+        ++it; sb += step;
+    }
+    for (; sb < n; sb += step, ++it) {                                           // the wave's last, partial chunks
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t q = sb + u * stride + lane;
+            const bool ok = q < n;
+            const int64_t qc = ok ? q : n - 1;                                   // a valid address, weight 0
+            add(val[qc], WEIGHTED ? sd[qc] : 1.0, ok);
+        }
+        fold();
+    }
+    return acc_finish<false>(st, WEIGHTED);
+}
+
 __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
                                                double* __restrict__ partial) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int ct = static_cast<int>(first % C);
-    const bool weighted = sd != nullptr;
-    constexpr int UN = 4;                                   // independent loads in flight per lane
-    MomAcc st = acc_zero();
-    int it = 0;
-    for (int64_t e = first; e < n; e += UN * stride, ++it) {
-        double vv[UN], sv[UN];
-        bool ok[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t q = e + u * stride;
-            ok[u] = q < n;
-            const int64_t qc = ok[u] ? q : e;                                 // tail: reload element e with weight 0 instead of branching
-            vv[u] = __builtin_nontemporal_load(val + qc);
-            sv[u] = sd ? __builtin_nontemporal_load(sd + qc) : 1.0;
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) acc_add(st, vv[u], weighted ? 1.0 / sv[u] : 1.0, sv[u], weighted, ok[u]);    // w = 1 / std, :342
-        if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) acc_fold(st);
-    }
-    const Mom mine[1] = {acc_finish(st, weighted)};
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    const int ct = static_cast<int>((sb0 + lane) % C);
+    const Mom mine[1] = {sd ? stats_loop<true>(val, sd, n, sb0, stride, lane) : stats_loop<false>(val, sd, n, sb0, stride, lane)};
     block_merge_store<1>(mine, ct, partial);
 }
 
 __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
                                                      double* __restrict__ out) {
-    for (int c = 0; c < C; ++c) {
-        const Mom m = grid_merge<1>(partial, nblocks, c, 0);
-        if (threadIdx.x == 0) {
-            double mean, sdv, err;
-            mom_finish(m, weighted != 0, mean, sdv, err);
-            out[c] = mean; out[C + c] = sdv; out[2 * C + c] = err;
-        }
+    const int c = blockIdx.x;                               // one workgroup per channel (they ran one after the other in one workgroup: 19 us)
+    const Mom m = grid_merge<1>(partial, nblocks, c, 0);
+    if (threadIdx.x == 0) {
+        double mean, sdv, err;
+        mom_finish(m, weighted != 0, mean, sdv, err);
+        out[c] = mean; out[C + c] = sdv; out[2 * C + c] = err;
     }
 }
 
@@ -303,17 +414,23 @@ __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ 
 // v_rsq_f64, about 26 bits; already the IEEE answer for 0, infinities and NaN) and two Newton steps, kept only when the estimate is a
 // finite non-zero number - 7 / 10 instructions instead of 11 (divide) / ~26 (sqrt + divide).
 __device__ __forceinline__ bool finite_nonzero(double x) { const double ax = fabs(x); return ax > 0.0 && ax < __builtin_huge_val(); }
+__device__ __forceinline__ double rcp_newton(double x, double r0) {
+    const double r = fma(fma(-x, r0, 1.0), r0, r0);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rsq_newton(double q, double y0) {
+    const double h = 0.5 * q;
+    const double y = y0 * fma(-h * y0, y0, 1.5);
+    return y * fma(-h * y, y, 1.5);
+}
 __device__ __forceinline__ double rcp_nr(double x) {
     const double r0 = __builtin_amdgcn_rcp(x);
-    double r = fma(fma(-x, r0, 1.0), r0, r0);
-    r = fma(fma(-x, r, 1.0), r, r);
+    const double r = rcp_newton(x, r0);
     return finite_nonzero(r0) ? r : r0;
 }
 __device__ __forceinline__ double rsqrt_nr(double q, double& root) {       // also sqrt(q) = q * rsqrt(q)
     const double y0 = __builtin_amdgcn_rsq(q);
-    const double h = 0.5 * q;
-    double y = y0 * fma(-h * y0, y0, 1.5);
-    y = y * fma(-h * y, y, 1.5);
+    const double y = rsq_newton(q, y0);
     const bool ok = finite_nonzero(y0);
     root = ok ? q * y : q;                                                   // sqrt(0) = 0, sqrt(inf) = inf, NaN stays NaN (q is a sum of squares)
     return ok ? y : y0;
@@ -322,73 +439,154 @@ __device__ __forceinline__ double rsqrt_nr(double q, double& root) {       // al
 // difference terms of one element (measurand.py:634-653) and the statistics weights 1 / std of both differences. One reciprocal
 // (1 / scale) and two reciprocal square roots per element: x / (m y) = x r, (ys x) / (m y^2) = ys x m r^2 with r = 1 / (m y), and
 // w = 1 / sqrt(q), std = q w - a few ulp from the reference's three divisions, two square roots and two reciprocals (the pair
-// kernels are FP64-VALU bound: 360 us for 1.6 GB on one pair); the statistics agree with the oracle to 1e-12.
-__device__ __forceinline__ void pair_terms(double xv, double xs, double yv, double ys, double mult, bool with_std,
-                                           double& a, double& as, double& wa, double& r, double& rs, double& wr) {
+// kernels are FP64-VALU bound); the statistics agree with the oracle to 1e-12.
+// GUARD = false leaves out the selects that keep the hardware estimate where it is 0 or infinite (scale, q = 0 or inf) and reports in
+// `special` whether this lane had such an estimate: the caller redoes the element with GUARD = true when any lane of the wave did
+// (wave-uniform branch; both forms give the same bits everywhere else, NaNs propagate through the Newton steps by themselves).
+constexpr int kClassZeroInf = 0x264;                    // v_cmp_class_f64 mask: -inf | -0 | +0 | +inf
+template <bool STD, bool GUARD>
+__device__ __forceinline__ void pair_terms(double xv, double xs, double yv, double ys, double mult,
+                                           double& a, double& as, double& wa, double& r, double& rs, double& wr, bool& special) {
     const double scale = mult * yv;                     // measurand.py:634
     a = xv - scale;                                     // :635
-    const double inv = rcp_nr(scale);
+    double inv;
+    if constexpr (GUARD) inv = rcp_nr(scale);
+    else {
+        const double r0 = __builtin_amdgcn_rcp(scale);
+        inv = rcp_newton(scale, r0);
+        special = __builtin_amdgcn_class(r0, kClassZeroInf);
+    }
     r = a * inv;                                        // :636
     wa = 1.0; wr = 1.0;
-    if (with_std) {
+    if constexpr (STD) {
         const double m1 = mult * ys;
         const double qa = xs * xs + m1 * m1;            // :652
-        wa = rsqrt_nr(qa, as);
         const double u1 = xs * inv;
         const double u2 = ((ys * xv) * mult) * (inv * inv);
         const double qr = u1 * u1 + u2 * u2;            // :653
-        wr = rsqrt_nr(qr, rs);
+        if constexpr (GUARD) {
+            wa = rsqrt_nr(qa, as);
+            wr = rsqrt_nr(qr, rs);
+        } else {
+            const double ya0 = __builtin_amdgcn_rsq(qa), yr0 = __builtin_amdgcn_rsq(qr);
+            wa = rsq_newton(qa, ya0); as = qa * wa;
+            wr = rsq_newton(qr, yr0); rs = qr * wr;
+            special = special || __builtin_amdgcn_class(ya0, kClassZeroInf) || __builtin_amdgcn_class(yr0, kClassZeroInf);
+        }
     }
+}
+
+// The element loop of both pair kernels for ONE wave: chunks of 64 consecutive elements starting at sb0, sb0 + stride, ... (sb0 and
+// stride wave-uniform, stride a multiple of C so that a lane's elements share a channel). Whole chunks take the select-free path;
+// the last, partial ones hand their missing elements to the accumulators as NaNs. Both Welford states fold every kMomBlock elements.
+// SX / SY: the first / second operand has a std image (compile-time, so that no load sits behind a branch: the waits in front of an
+// iteration's arithmetic can then leave the NEXT iteration's loads in flight); statistics are weighted when either has one.
+constexpr int kPairUN = 2;                     // 64-element chunks per wave iteration (sb and sb + stride)
+template <bool STD>
+__device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mult, const double (&xv)[kPairUN], const double (&xs)[kPairUN],
+                                             const double (&yv)[kPairUN], const double (&ys)[kPairUN]) {
+#pragma unroll
+    for (int u = 0; u < kPairUN; ++u) {
+        double av, as = 0.0, wa, rv, rs = 0.0, wr;
+        bool special = false;
+        pair_terms<STD, false>(xv[u], xs[u], yv[u], ys[u], mult, av, as, wa, rv, rs, wr, special);
+        if (__builtin_amdgcn_ballot_w64(special) != 0)                           // a zero / infinite scale or variance somewhere in the wave
+            pair_terms<STD, true>(xv[u], xs[u], yv[u], ys[u], mult, av, as, wa, rv, rs, wr, special);
+        acc_add_pair<STD>(st[0], av, wa, as);
+        acc_add_pair<STD>(st[1], rv, wr, rs);
+    }
+    if ((it & (kMomBlock / kPairUN - 1)) == kMomBlock / kPairUN - 1) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }
+}
+
+// the wave's last, partial chunks (from iteration `it` at element sb on), then the final fold
+template <bool SX, bool SY>
+__device__ __forceinline__ void pair_tail(MomAcc (&st)[2], int it, int64_t sb, const double* x, const double* sx, const double* y,
+                                          const double* sy, double mult, int64_t n, int64_t stride, uint32_t lane, Mom (&mine)[2]) {
+    constexpr bool STD = SX || SY;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (; sb < n; sb += kPairUN * stride, ++it) {
+        double xv[kPairUN], yv[kPairUN], xs[kPairUN], ys[kPairUN];
+#pragma unroll
+        for (int u = 0; u < kPairUN; ++u) {
+            const int64_t q = sb + u * stride + lane;
+            const bool ok = q < n;
+            const int64_t qc = ok ? q : n - 1;                                   // a valid address; the element enters as NaN
+            xv[u] = ok ? x[qc] : nan;
+            yv[u] = y[qc];
+            xs[u] = SX ? sx[qc] : 0.0;
+            ys[u] = SY ? sy[qc] : 0.0;
+            if (STD) xs[u] = ok ? xs[u] : nan;
+        }
+        pair_process<STD>(st, it, mult, xv, xs, yv, ys);
+    }
+    mine[0] = acc_finish<true>(st[0], STD);
+    mine[1] = acc_finish<true>(st[1], STD);
+}
+
+template <bool SX, bool SY, bool NT>
+__device__ __forceinline__ void pair_loop(const double* x, const double* sx, const double* y, const double* sy, double mult, int64_t n,
+                                          int64_t sb0, int64_t stride, uint32_t lane, Mom (&mine)[2]) {
+    constexpr bool STD = SX || SY;
+    constexpr int UN = kPairUN;
+    MomAcc st[2] = {acc_zero(), acc_zero()};                                   // absolute | relative difference
+    const uint32_t lo = lane * 8u;
+    int it = 0;
+    int64_t sb = sb0;
+    // whole chunks (every lane exists): the next iteration's loads are issued before the current one's arithmetic (two register sets,
+    // the loop written out twice) - a wave that waits for its loads at the top of every iteration leaves the VALU idle for the latency
+    auto whole = [&](int64_t b) { return b + (UN - 1) * stride + 64 <= n; };
+    auto load = [&](int64_t b, double (&xv)[UN], double (&xs)[UN], double (&yv)[UN], double (&ys)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t cb = b + u * stride;                                   // scalar
+            xv[u] = ld_f64_sv<NT>(x + cb, lo);
+            yv[u] = ld_f64_sv<NT>(y + cb, lo);
+            xs[u] = SX ? ld_f64_sv<NT>(sx + cb, lo) : 0.0;
+            ys[u] = SY ? ld_f64_sv<NT>(sy + cb, lo) : 0.0;
+        }
+    };
+    const int64_t step = UN * stride;
+    double xa[UN], ya[UN], sxa[UN], sya[UN], xb[UN], yb[UN], sxb[UN], syb[UN];
+    // (the prefetch is unconditional - past the last whole iteration it re-reads the current one and the values are dropped: a branch
+    // around the loads would make the compiler's wait counts assume they were skipped and wait for them before the arithmetic)
+    if (whole(sb)) load(sb, xa, sxa, ya, sya);
+    while (whole(sb)) {
+        load(whole(sb + step) ? sb + step : sb, xb, sxb, yb, syb);
+        pair_process<STD>(st, it, mult, xa, sxa, ya, sya);
+        ++it; sb += step;
+        if (!whole(sb)) break;
+        load(whole(sb + step) ? sb + step : sb, xa, sxa, ya, sya);
+        pair_process<STD>(st, it, mult, xb, sxb, yb, syb);
+        ++it; sb += step;
+    }
+    pair_tail<SX, SY>(st, it, sb, x, sx, y, sy, mult, n, stride, lane, mine);
 }
 
 __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x, const double* __restrict__ sx,
                                                     const double* __restrict__ y, const double* __restrict__ sy, double mult,
                                                     int64_t n, int C, double* __restrict__ partial) {
-    const bool with_std = sx || sy;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;       // a multiple of C (see k_stats)
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int ct = static_cast<int>(first % C);
-    MomAcc st[2] = {acc_zero(), acc_zero()};                                   // absolute | relative difference
-    constexpr int UN = 2;
-    int it = 0;
-    for (int64_t e0 = first; e0 < n; e0 += UN * stride, ++it) {
-        double xv[UN], yv[UN], xs[UN], ys[UN];
-        bool ok[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t q = e0 + u * stride;
-            ok[u] = q < n;
-            const int64_t qc = ok[u] ? q : e0;                                  // tail: a valid address, weight 0
-            xv[u] = __builtin_nontemporal_load(x + qc);
-            yv[u] = __builtin_nontemporal_load(y + qc);
-            xs[u] = sx ? __builtin_nontemporal_load(sx + qc) : 0.0;
-            ys[u] = sy ? __builtin_nontemporal_load(sy + qc) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            double a, as = 0.0, wa, r, rs = 0.0, wr;
-            pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, a, as, wa, r, rs, wr);
-            acc_add(st[0], a, wa, as, with_std, ok[u]);
-            acc_add(st[1], r, wr, rs, with_std, ok[u]);
-        }
-        if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold(st[0]); acc_fold(st[1]); }
-    }
-    const Mom mine[2] = {acc_finish(st[0], with_std), acc_finish(st[1], with_std)};
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    const int ct = static_cast<int>((sb0 + lane) % C);
+    Mom mine[2];
+    if (sx && sy) pair_loop<true, true, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
+    else if (sx) pair_loop<true, false, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
+    else if (sy) pair_loop<false, true, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
+    else pair_loop<false, false, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
     block_merge_store<2>(mine, ct, partial);
 }
 
 __global__ __launch_bounds__(256) void k_pair_final(const double* __restrict__ partial, int nblocks, int C, int weighted,
                                                     double* __restrict__ out) {
-    for (int h = 0; h < 2; ++h)
-        for (int c = 0; c < C; ++c) {
-            const Mom m = grid_merge<2>(partial, nblocks, c, h);
-            if (threadIdx.x == 0) {
-                double mean, sdv, err;
-                mom_finish(m, weighted != 0, mean, sdv, err);
-                double* o = out + 3 * C * h;
-                o[c] = mean; o[C + c] = sdv; o[2 * C + c] = err;
-            }
-        }
+    const int h = blockIdx.x / C, c = blockIdx.x % C;       // one workgroup per (difference kind, channel)
+    const Mom m = grid_merge<2>(partial, nblocks, c, h);
+    if (threadIdx.x == 0) {
+        double mean, sdv, err;
+        mom_finish(m, weighted != 0, mean, sdv, err);
+        double* o = out + 3 * C * h;
+        o[c] = mean; o[C + c] = sdv; o[2 * C + c] = err;
+    }
 }
 
 // ---- all exposure pairs of a stack in one launch ------------------------------------------------
@@ -415,36 +613,106 @@ __global__ __launch_bounds__(1024) void k_pairs_stats(const PairsK a, double* __
     const double* sx = a.with_std ? a.sd[a.pi[wave]] : nullptr;
     const double* sy = a.with_std ? a.sd[a.pj[wave]] : nullptr;
     const double mult = a.mult[wave];
-    const bool with_std = a.with_std != 0;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 64;                               // a multiple of C (grid: multiple of 12)
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * 64 + lane;
-    const int ct = static_cast<int>(first % a.C);
-    MomAcc st[2] = {acc_zero(), acc_zero()};                                                   // absolute | relative difference
-    constexpr int UN = 2;
-    int it = 0;
-    for (int64_t e0 = first; e0 < a.n; e0 += UN * stride, ++it) {
-        double xv[UN], yv[UN], xs[UN], ys[UN];
-        bool ok[UN];
+    const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * 64;
+    const int ct = static_cast<int>((sb0 + lane) % a.C);
+    Mom mine[2];
+    // (default cache policy on the loads: the other waves of the workgroup re-read these lines)
+    if (a.with_std) pair_loop<true, true, false>(x, sx, y, sy, mult, a.n, sb0, stride, lane, mine);
+    else pair_loop<false, false, false>(x, sx, y, sy, mult, a.n, sb0, stride, lane, mine);
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t q = e0 + u * stride;
-            ok[u] = q < a.n;
-            const int64_t qc = ok[u] ? q : e0;                                                 // tail: a valid address, weight 0
-            xv[u] = x[qc];                                                                     // (default cache policy: the other waves re-read these lines)
-            yv[u] = y[qc];
-            xs[u] = sx ? sx[qc] : 0.0;
-            ys[u] = sy ? sy[qc] : 0.0;
-        }
+    for (int c = 0; c < HM_MAX_CHANNELS; ++c) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            double av, as = 0.0, wa, rv, rs = 0.0, wr;
-            pair_terms(xv[u], xs[u], yv[u], ys[u], mult, with_std, av, as, wa, rv, rs, wr);
-            acc_add(st[0], av, wa, as, with_std, ok[u]);
-            acc_add(st[1], rv, wr, rs, with_std, ok[u]);
+        for (int q = 0; q < 2; ++q) {
+            Mom m = c == ct ? mine[q] : mom_zero();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = mom_merge(m, mom_shfl_down(m, off));
+            if (lane == 0)
+                mom_store(partial + (((static_cast<int64_t>(blockIdx.x) * a.n_pairs + wave) * HM_MAX_CHANNELS + c) * 2 + q) * kMomVals, m);
         }
-        if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold(st[0]); acc_fold(st[1]); }
     }
-    const Mom mine[2] = {acc_finish(st[0], with_std), acc_finish(st[1], with_std)};
+}
+
+// The same statistics with the frames staged through LDS (the launch's usual shape: N >= 3 frames, all their pairs). In k_pairs_stats
+// every wave loads its own operands: 4 global loads per wave and chunk, 60 per workgroup for 14 distinct streams, and only the waves'
+// rough lock-step makes the other 46 hit in L1 / L2. Here the workgroup's threads copy each stream's two 512-byte chunks of an
+// iteration ONCE into LDS (16-byte items; item t of an iteration is stream t / 64, chunk (t % 64) / 32, piece t % 32 - NI = 1 or 2
+// items per thread) one iteration ahead of its use into one of three LDS stages, the loads in flight during the arithmetic before;
+// after one barrier per iteration every wave reads its pair's operands with conflict-free ds_read_b64. HBM sees the read-once
+// traffic, 1 KB per stream in flight per CU for a whole iteration, instead of 60 wave loads that mostly hit in cache.
+template <bool STD, int NI>
+__global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_frames, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char stage_mem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));       // = pair index, wave-uniform
+    const int pi = a.pi[wave], pj = a.pj[wave];
+    const double mult = a.mult[wave];
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 64;                               // a multiple of C (grid: multiple of 12)
+    const int64_t step = kPairUN * stride;
+    const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * 64;
+    const int ct = static_cast<int>((sb0 + lane) % a.C);
+    const int n_streams = n_frames * (STD ? 2 : 1);
+    const uint32_t stage_bytes = static_cast<uint32_t>(n_streams) * 1024u;
+    const int n_items = n_streams * 64;
+    // this thread's items: source pointer at iteration 0 and LDS byte offset inside a stage
+    const double* src[NI];
+    bool have[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int item = static_cast<int>(threadIdx.x) + k * static_cast<int>(blockDim.x);
+        have[k] = item < n_items;
+        const int it_ = have[k] ? item : 0;
+        const int sidx = it_ >> 6, u = (it_ >> 5) & 1, piece = it_ & 31;
+        const double* base = sidx < n_frames ? a.val[sidx] : a.sd[sidx - n_frames];
+        src[k] = base + sb0 + u * stride + 2 * piece;
+    }
+    auto whole = [&](int64_t b) { return b + (kPairUN - 1) * stride + 64 <= a.n; };
+    auto fetch = [&](int64_t delta, f64x2 (&r)[NI]) {                                           // delta = element offset of the iteration from sb0
+#pragma unroll
+        for (int k = 0; k < NI; ++k) r[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src[k] + delta));   // read once
+    };
+    auto stash = [&](int stage, const f64x2 (&r)[NI]) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+            if (have[k]) *reinterpret_cast<f64x2*>(stage_mem + stage * stage_bytes + (threadIdx.x + k * blockDim.x) * 16u) = r[k];
+    };
+    MomAcc st[2] = {acc_zero(), acc_zero()};
+    const uint32_t ox = static_cast<uint32_t>(pi) * 1024u + lane * 8u, oy = static_cast<uint32_t>(pj) * 1024u + lane * 8u;
+    const uint32_t osx = ox + static_cast<uint32_t>(n_frames) * 1024u, osy = oy + static_cast<uint32_t>(n_frames) * 1024u;
+    auto compute = [&](int stage, int it) {
+        const char* sm = stage_mem + stage * stage_bytes;
+        double xv[kPairUN], yv[kPairUN], xs[kPairUN], ys[kPairUN];
+#pragma unroll
+        for (int u = 0; u < kPairUN; ++u) {
+            xv[u] = *reinterpret_cast<const double*>(sm + ox + u * 512);
+            yv[u] = *reinterpret_cast<const double*>(sm + oy + u * 512);
+            xs[u] = STD ? *reinterpret_cast<const double*>(sm + osx + u * 512) : 0.0;
+            ys[u] = STD ? *reinterpret_cast<const double*>(sm + osy + u * 512) : 0.0;
+        }
+        pair_process<STD>(st, it, mult, xv, xs, yv, ys);
+    };
+    // Whole iterations (sb is the same for every wave of the workgroup, so the trip count is too). Iteration k: the registers hold
+    // iteration k + 1 (loaded during iteration k - 1's arithmetic) -> LDS stage (k + 1) % 3; load iteration k + 2; barrier; compute
+    // iteration k from stage k % 3. Three stages: a fast wave writes stage k + 1 while a slow one may still read stage k - 1.
+    // One register set and one loop body: the only loads outstanding at the wait are the ones it is for. Past the last whole
+    // iteration the prefetch re-reads the current one (dropped) - no branch around a load, see pair_loop.
+    int64_t sb = sb0;
+    int it = 0, stage = 0;
+    f64x2 r[NI];
+    auto clamp = [&](int64_t b) { return (whole(b) ? b : sb) - sb0; };
+    if (whole(sb)) { fetch(0, r); stash(0, r); fetch(clamp(sb + step), r); }
+    while (whole(sb)) {
+        const int nxt = stage == 2 ? 0 : stage + 1;
+        stash(nxt, r);
+        fetch(clamp(sb + 2 * step), r);
+        __syncthreads();
+        compute(stage, it);
+        ++it; sb += step; stage = nxt;
+    }
+    Mom mine[2];
+    const double* x = a.val[pi];
+    const double* y = a.val[pj];
+    pair_tail<STD, STD>(st, it, sb, x, STD ? a.sd[pi] : nullptr, y, STD ? a.sd[pj] : nullptr, mult, a.n, stride, lane, mine);
 #pragma unroll
     for (int c = 0; c < HM_MAX_CHANNELS; ++c) {
 #pragma unroll
@@ -463,28 +731,25 @@ __global__ __launch_bounds__(256) void k_pairs_final(const double* __restrict__ 
                                                      double* __restrict__ out) {
     __shared__ double tree[256][kMomVals];
     const int pair = blockIdx.x;
-    for (int h = 0; h < 2; ++h)
-        for (int c = 0; c < C; ++c) {
-            Mom m = mom_zero();
-            for (int b = threadIdx.x; b < nblocks; b += 256)
-                m = mom_merge(m, mom_load(partial + (((static_cast<int64_t>(b) * n_pairs + pair) * HM_MAX_CHANNELS + c) * 2 + h) * kMomVals));
-            __syncthreads();
-            mom_store(tree[threadIdx.x], m);
-            __syncthreads();
-            for (int span = 128; span > 0; span >>= 1) {
-                if (static_cast<int>(threadIdx.x) < span) {
-                    const Mom r = mom_merge(mom_load(tree[threadIdx.x]), mom_load(tree[threadIdx.x + span]));
-                    mom_store(tree[threadIdx.x], r);
-                }
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                double mean, sdv, err;
-                mom_finish(mom_load(tree[0]), weighted != 0, mean, sdv, err);
-                double* o = out + static_cast<int64_t>(pair) * 6 * C + 3 * C * h;
-                o[c] = mean; o[C + c] = sdv; o[2 * C + c] = err;
-            }
+    const int h = blockIdx.y / C, c = blockIdx.y % C;       // one workgroup per (pair, difference kind, channel)
+    Mom m = mom_zero();
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        m = mom_merge(m, mom_load(partial + (((static_cast<int64_t>(b) * n_pairs + pair) * HM_MAX_CHANNELS + c) * 2 + h) * kMomVals));
+    mom_store(tree[threadIdx.x], m);
+    __syncthreads();
+    for (int span = 128; span > 0; span >>= 1) {
+        if (static_cast<int>(threadIdx.x) < span) {
+            const Mom r = mom_merge(mom_load(tree[threadIdx.x]), mom_load(tree[threadIdx.x + span]));
+            mom_store(tree[threadIdx.x], r);
         }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double mean, sdv, err;
+        mom_finish(mom_load(tree[0]), weighted != 0, mean, sdv, err);
+        double* o = out + static_cast<int64_t>(pair) * 6 * C + 3 * C * h;
+        o[c] = mean; o[C + c] = sdv; o[2 * C + c] = err;
+    }
 }
 
 // ---- per-channel histogram (compute_channel_histogram, modules/measurand.py:430-469) ----------------
@@ -652,7 +917,7 @@ extern "C" int hm_channel_statistics(const double* val, const double* std, int64
     const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, val, std, n, C, partial);
-    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, st, partial, grid, C, std ? 1 : 0, out);
+    hipLaunchKernelGGL(k_stats_final, dim3(C), dim3(256), 0, st, partial, grid, C, std ? 1 : 0, out);
     return launch_status();
 }
 
@@ -667,7 +932,7 @@ extern "C" int hm_pair_statistics(const double* x, const double* sx, const doubl
     const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(k_pair_stats, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, partial);
-    hipLaunchKernelGGL(k_pair_final, dim3(1), dim3(256), 0, st, partial, grid, C, (sx || sy) ? 1 : 0, out);
+    hipLaunchKernelGGL(k_pair_final, dim3(2 * C), dim3(256), 0, st, partial, grid, C, (sx || sy) ? 1 : 0, out);
     return launch_status();
 }
 
@@ -699,8 +964,23 @@ extern "C" int hm_pairs_statistics(const double* const* vals, const double* cons
         const int np = n_pairs - p0 < HM_PAIRS_MAX ? n_pairs - p0 : HM_PAIRS_MAX;
         k.n_pairs = np;
         for (int p = 0; p < np; ++p) { k.pi[p] = pair_i[p0 + p]; k.pj[p] = pair_j[p0 + p]; k.mult[p] = multipliers[p0 + p]; }
-        hipLaunchKernelGGL(k_pairs_stats, dim3(grid), dim3(64 * np), 0, st, k, partial);
-        hipLaunchKernelGGL(k_pairs_final, dim3(np), dim3(256), 0, st, partial, grid, np, C, k.with_std, out + static_cast<int64_t>(p0) * 6 * C);
+        // frames through LDS when a workgroup's threads can copy an iteration's 64 * n_streams 16-byte items with at most two each
+        const int n_streams = n_frames * (stds ? 2 : 1);
+        const int items = n_streams * 64, threads = 64 * np;
+        bool al16 = true;
+        for (int i = 0; i < n_frames; ++i) al16 = al16 && aligned(vals[i], 16) && (!stds || aligned(stds[i], 16));
+        if (al16 && items <= 2 * threads && n_streams <= 21) {                                   // 3 stages x n_streams KB <= 64 KB of LDS
+            const size_t lds = 3u * static_cast<size_t>(n_streams) * 1024u;
+            if (stds) {
+                if (items <= threads) hipLaunchKernelGGL((k_pairs_stats_lds<true, 1>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
+                else hipLaunchKernelGGL((k_pairs_stats_lds<true, 2>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
+            } else {
+                if (items <= threads) hipLaunchKernelGGL((k_pairs_stats_lds<false, 1>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
+                else hipLaunchKernelGGL((k_pairs_stats_lds<false, 2>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
+            }
+        } else
+            hipLaunchKernelGGL(k_pairs_stats, dim3(grid), dim3(64 * np), 0, st, k, partial);
+        hipLaunchKernelGGL(k_pairs_final, dim3(np, 2 * C), dim3(256), 0, st, partial, grid, np, C, k.with_std, out + static_cast<int64_t>(p0) * 6 * C);
     }
     return launch_status();
 }

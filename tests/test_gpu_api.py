@@ -458,3 +458,53 @@ def test_one_pass_statistics_are_stable(weighted):
     # bit-reproducible: a second launch gives the same bits
     again = engine.channel_statistics(torch.as_tensor(v, device="cuda"), None if s is None else torch.as_tensor(s, device="cuda"))
     assert torch.equal(again["std"], got["std"]) and torch.equal(again["mean"], got["mean"])
+
+
+@pytest.mark.parametrize("with_std", [True, False])
+def test_pair_statistics_zero_and_infinite_operands(with_std):
+    """hm_pair_statistics / hm_pairs_statistics on operands whose hardware reciprocal / reciprocal-square-root estimates are 0 or
+    infinite (y = 0 -> scale = 0; both stds 0 -> variance 0; an infinite value; an infinite std): the wave that meets one redoes the
+    element with the guarded forms. Compared with the unfused HIP path (difference images by IEEE divisions + per-image statistics):
+    the same NaN / inf pattern per output and 1e-12 where finite; odd sizes, so the partial-chunk path is taken too. A second image
+    keeps the special values in its first lanes only, so one workgroup mixes clean and special waves."""
+    from camera_linearity_amd import engine
+    rng = np.random.default_rng(5)
+    for shape, special_rows in (((33, 21, 3), None), ((257, 129, 3), 2)):
+        x = 0.2 + rng.random(shape)
+        y = 0.3 + rng.random(shape)
+        sx = 0.01 + 0.01 * rng.random(shape)
+        sy = 0.01 + 0.01 * rng.random(shape)
+        region = slice(None) if special_rows is None else slice(0, special_rows)
+        m = rng.random(shape)
+        pick = np.zeros(shape, dtype=bool)
+        pick[region] = True
+        y[pick & (m < 0.05)] = 0.0
+        both0 = pick & (m > 0.05) & (m < 0.10)
+        sx[both0] = 0.0
+        sy[both0] = 0.0
+        x[pick & (m > 0.10) & (m < 0.12)] = np.inf
+        sx[pick & (m > 0.12) & (m < 0.14)] = np.inf
+        x[pick & (m > 0.14) & (m < 0.20)] = np.nan
+        # channel 2 stays clean so that at least one output column is finite
+        for a_, fill in ((x, 0.5), (y, 0.6), (sx, 0.01), (sy, 0.02)):
+            a_[..., 2] = np.where(np.isfinite(a_[..., 2]) & (a_[..., 2] != 0.0), a_[..., 2], fill)
+        up = lambda a: torch.as_tensor(a, device="cuda")   # noqa: E731
+        gx, gy = up(x), up(y)
+        gsx, gsy = (up(sx), up(sy)) if with_std else (None, None)
+        mult = 0.37
+        fa, fr = engine.pair_statistics(gx, gsx, gy, gsy, mult)
+        ad, ads, rd, rds = engine.compute_difference(gx, gsx, gy, gsy, mult)
+        ua, ur = engine.channel_statistics(ad, ads), engine.channel_statistics(rd, rds)
+        both = engine.pairs_statistics([gx, gy], None if not with_std else [gsx, gsy], [(0, 1, mult)])
+        for f, u, p in ((fa, ua, both[0][0]), (fr, ur, both[0][1])):
+            for key in ("mean", "std", "error"):
+                if u[key] is None:
+                    assert f[key] is None
+                    continue
+                got, ref, allp = f[key].cpu().numpy(), u[key].cpu().numpy(), p[key].cpu().numpy()
+                assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref)), (key, got, ref)
+                fin = np.isfinite(ref)
+                assert fin[2]
+                np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-12)
+                assert np.array_equal(np.isnan(allp), np.isnan(ref)) and np.array_equal(np.isinf(allp), np.isinf(ref)), (key, allp, ref)
+                np.testing.assert_allclose(allp[fin], ref[fin], rtol=1e-12)      # the all-pairs kernel (another partition of the elements)

@@ -18,6 +18,7 @@ H, W = 4096, 4096
 E = H * W * 3
 frames, stds, t = synthetic_stack_device(7, 2, H, W, device=dev, with_std=True)
 dn, sd = frames[1], stds[1]
+sd2 = stds[0]          # the second operand's std is its OWN buffer: passing `sd` twice halves the real traffic of a 4-stream kernel
 v = engine.u8_to_unit(dn)
 v2 = engine.u8_to_unit(frames[0]) + 0.25
 icrf, diff = synthetic_icrf()
@@ -35,9 +36,9 @@ CASES = {
     "linearize f64 input (round-half-even index)": (lambda: engine.linearize(v, None, icrf), E * 16),
     "gaussian weight u8 LUT (w, dw)": (lambda: engine.gaussian_weight(dn), E * 17),
     "gaussian weight f64 analytic (w, dw)": (lambda: engine.gaussian_weight(v), E * 24),
-    "__add__ with std (measurand.py:106)": (lambda: engine.elementwise_binary(nat.HM_OP_ADD, v, sd, v2, sd), E * 48),
-    "__mul__ with std": (lambda: engine.elementwise_binary(nat.HM_OP_MUL, v, sd, v2, sd), E * 48),
-    "__truediv__ with std": (lambda: engine.elementwise_binary(nat.HM_OP_DIV, v, sd, v2, sd), E * 48),
+    "__add__ with std (measurand.py:106)": (lambda: engine.elementwise_binary(nat.HM_OP_ADD, v, sd, v2, sd2), E * 48),
+    "__mul__ with std": (lambda: engine.elementwise_binary(nat.HM_OP_MUL, v, sd, v2, sd2), E * 48),
+    "__truediv__ with std": (lambda: engine.elementwise_binary(nat.HM_OP_DIV, v, sd, v2, sd2), E * 48),
     "__pow__ array exponent (generic pow), no std": (lambda: engine.elementwise_binary(nat.HM_OP_POW, v2, None, torch.tensor([2.0], device=dev, dtype=torch.float64), None), E * 16),
     "__pow__ scalar 2, no std (S ** 2, exposure_series.py:343)": (lambda: engine.pow_scalar(v2, None, 2.0), E * 16),
     "__pow__ scalar 1/2, no std (exposure_series.py:394)": (lambda: engine.pow_scalar(v2, None, 0.5), E * 16),
@@ -48,8 +49,9 @@ CASES = {
     "roi_mean u8 (flat ROI 20 %)": (lambda: engine.roi_mean(flat, x0, x1, y0, y1), (x1 - x0) * (y1 - y0) * 3),
     "channel_statistics weighted (one pass)": (lambda: engine.channel_statistics(v, sd), E * 16),
     "channel_statistics unweighted (one pass)": (lambda: engine.channel_statistics(v, None), E * 8),
-    "pair_statistics weighted (one pass, fused)": (lambda: engine.pair_statistics(v, sd, v2, sd, 0.5), E * 32),
-    "compute_difference with std": (lambda: engine.compute_difference(v, sd, v2, sd, 0.5), E * 64),
+    "pair_statistics weighted (one pass, fused)": (lambda: engine.pair_statistics(v, sd, v2, sd2, 0.5), E * 32),
+    "pair_statistics unweighted (one pass, fused)": (lambda: engine.pair_statistics(v, None, v2, None, 0.5), E * 16),
+    "compute_difference with std": (lambda: engine.compute_difference(v, sd, v2, sd2, 0.5), E * 64),
 }
 
 

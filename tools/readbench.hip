@@ -1,0 +1,85 @@
+// readbench.hip - read-only streaming ceiling for the reduction kernels (hm_stats.hip): S float64 streams summed, VEC doubles per
+// lane and load, UN wave-chunks in flight per stream, nontemporal or plain loads, G workgroups. Prints TB/s per shape.
+//   hipcc -O3 --offload-arch=gfx950 tools/readbench.hip -o tools/bin/readbench && tools/bin/readbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+struct P { const double* s[4]; int64_t n; double* out; };
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <int S, int VEC, bool NT, int UN>
+__global__ __launch_bounds__(256) void k(const P a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t chunk = 64 * VEC;
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * chunk;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4 * chunk;
+    double acc = 0.0;
+    for (int64_t b = wave0; b + (UN - 1) * stride + chunk <= a.n; b += UN * stride) {
+        double v[S][UN][VEC];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const double* p = a.s[s] + b + u * stride + lane * VEC;
+                if constexpr (VEC == 2) {
+                    const f64x2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(p)) : *reinterpret_cast<const f64x2*>(p);
+                    v[s][u][0] = t.x; v[s][u][1] = t.y;
+                } else {
+                    v[s][u][0] = NT ? __builtin_nontemporal_load(p) : *p;
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc += v[s][u][e];
+    }
+    a.out[static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x] = acc;
+}
+
+template <int S, int VEC, bool NT, int UN>
+static void run(const P& p, int grid, const char* name) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<S, VEC, NT, UN>), dim3(grid), dim3(256), 0, 0, p);
+    std::vector<float> t;
+    for (int r = 0; r < 5; ++r) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k<S, VEC, NT, UN>), dim3(grid), dim3(256), 0, 0, p);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); t.push_back(ms / 20);
+    }
+    std::sort(t.begin(), t.end());
+    const double bytes = static_cast<double>(S) * p.n * 8;
+    printf("%-34s grid %5d  %7.1f us  %5.2f TB/s\n", name, grid, t[2] * 1e3, bytes / (t[2] * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
+int main() {
+    const int64_t n = 4096ll * 4096 * 3;
+    P p{};
+    p.n = n;
+    for (int s = 0; s < 4; ++s) { hipMalloc(const_cast<double**>(&p.s[s]), n * 8); hipMemset(const_cast<double*>(p.s[s]), 0, n * 8); }
+    hipMalloc(&p.out, 8192 * 256 * 8);
+    // warm the clock
+    for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL((k<1, 1, true, 4>), dim3(2048), dim3(256), 0, 0, p);
+    hipDeviceSynchronize();
+    for (int grid : {1024, 2040, 4096, 8192}) {
+        run<1, 1, true, 4>(p, grid, "1 stream  8B nt UN4");
+        run<1, 1, true, 8>(p, grid, "1 stream  8B nt UN8");
+        run<1, 2, true, 4>(p, grid, "1 stream 16B nt UN4");
+        run<1, 2, true, 8>(p, grid, "1 stream 16B nt UN8");
+        run<1, 2, false, 4>(p, grid, "1 stream 16B plain UN4");
+        run<2, 1, true, 4>(p, grid, "2 streams 8B nt UN4");
+        run<2, 2, true, 4>(p, grid, "2 streams 16B nt UN4");
+        run<4, 1, true, 2>(p, grid, "4 streams 8B nt UN2");
+        run<4, 1, true, 4>(p, grid, "4 streams 8B nt UN4");
+        run<4, 2, true, 2>(p, grid, "4 streams 16B nt UN2");
+        run<4, 2, false, 2>(p, grid, "4 streams 16B plain UN2");
+    }
+    return 0;
+}
