@@ -1500,7 +1500,10 @@ static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map ? 4 : 1) * st
 template <int NF, int U, int PF, int MAP>
 static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
     const int64_t units = k.n_elems / (U * (MAP ? 4 : 1) * static_cast<int>(kSub));
-    unsigned grid = MAP ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, 8);   // 8 workgroups of 4 waves per CU
+#ifndef HM_VAL3_WG_PER_CU
+#define HM_VAL3_WG_PER_CU 8
+#endif
+    unsigned grid = MAP ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, HM_VAL3_WG_PER_CU);   // 8 workgroups of 4 waves per CU
     if (U % 3 != 0 && grid >= 3) grid -= grid % 3;          // the unit index must advance by a multiple of 3 per iteration (see the kernel)
     if (grid == 0) grid = 1;
     if (describe_only("merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;

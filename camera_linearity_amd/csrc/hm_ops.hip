@@ -68,6 +68,39 @@ __global__ __launch_bounds__(256) void k_binary(const double* __restrict__ x1, c
     }
 }
 
+// Dense operands of one shape (what the reference's operators see on image stacks): two elements per lane, 16-byte nontemporal
+// accesses, the presence of each operand's std a compile-time flag - no per-element index arithmetic, no load behind a branch.
+// The general kernel above (one element per lane and step, strided offsets) measured 0.62-0.64 of 8 TB/s on six dense streams.
+template <int OP, bool S1, bool S2>
+__global__ __launch_bounds__(256) void k_binary_dense(const double* __restrict__ x1, const double* __restrict__ s1,
+                                                      const double* __restrict__ x2, const double* __restrict__ s2,
+                                                      double* __restrict__ out, double* __restrict__ out_std, int64_t n) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    constexpr bool STD = S1 || S2;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t pairs = n / 2;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < pairs; q += stride) {
+        const f64x2 a = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x1) + q);
+        const f64x2 c = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x2) + q);
+        f64x2 sa = {0.0, 0.0}, sc = {0.0, 0.0};
+        if constexpr (S1) sa = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s1) + q);
+        if constexpr (S2) sc = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s2) + q);
+        f64x2 r, rs = {0.0, 0.0};
+        double r0, r1, e0 = 0.0, e1 = 0.0;
+        binary_eval<OP>(a.x, sa.x, c.x, sc.x, STD, r0, e0);
+        binary_eval<OP>(a.y, sa.y, c.y, sc.y, STD, r1, e1);
+        r.x = r0; r.y = r1; rs.x = e0; rs.y = e1;
+        __builtin_nontemporal_store(r, reinterpret_cast<f64x2*>(out) + q);
+        if constexpr (STD) __builtin_nontemporal_store(rs, reinterpret_cast<f64x2*>(out_std) + q);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double r, e = 0.0;
+        binary_eval<OP>(x1[n - 1], S1 ? s1[n - 1] : 0.0, x2[n - 1], S2 ? s2[n - 1] : 0.0, STD, r, e);
+        out[n - 1] = r;
+        if constexpr (STD) out_std[n - 1] = e;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_unary(int op, const double* __restrict__ x, const double* __restrict__ s,
                                                double* __restrict__ out, double* __restrict__ out_std, int64_t n) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -223,8 +256,25 @@ extern "C" int hm_binary_op(int op, const double* x1, const double* s1, const do
     }
     b.contiguous = dense ? 1 : 0;
     if (n == 0) return HM_OK;
-    const unsigned grid = stream_grid(n, 256, 8);
     hipStream_t st = as_stream(stream);
+    const bool al16 = aligned(x1, 16) && aligned(x2, 16) && aligned(out_val, 16) && (!s1 || aligned(s1, 16)) && (!s2 || aligned(s2, 16)) &&
+                      (!out_std || aligned(out_std, 16));
+    if (dense && al16 && op != HM_OP_POW) {
+        const unsigned dgrid = stream_grid((n + 1) / 2, 256, 8);
+#define HM_BIND(O, A, B) hipLaunchKernelGGL((k_binary_dense<O, A, B>), dim3(dgrid), dim3(256), 0, st, x1, s1, x2, s2, out_val, out_std, n)
+#define HM_BINS(O) do { if (s1 && s2) HM_BIND(O, true, true); else if (s1) HM_BIND(O, true, false); else if (s2) HM_BIND(O, false, true); \
+                        else HM_BIND(O, false, false); } while (0)
+        switch (op) {
+            case HM_OP_ADD: HM_BINS(HM_OP_ADD); break;
+            case HM_OP_SUB: HM_BINS(HM_OP_SUB); break;
+            case HM_OP_MUL: HM_BINS(HM_OP_MUL); break;
+            default:        HM_BINS(HM_OP_DIV); break;
+        }
+#undef HM_BINS
+#undef HM_BIND
+        return launch_status();
+    }
+    const unsigned grid = stream_grid(n, 256, 8);
 #define HM_BIN(O) hipLaunchKernelGGL(k_binary<O>, dim3(grid), dim3(256), 0, st, x1, s1, x2, s2, out_val, out_std, n, b)
     switch (op) {
         case HM_OP_ADD: HM_BIN(HM_OP_ADD); break;
