@@ -18,8 +18,10 @@ def synthetic_exposures(n: int) -> np.ndarray:
 
 
 def synthetic_stack_device(seed: int, n: int, h: int, w: int, c: int = 3, device="cuda", with_std: bool = False,
-                           uniform_dn: bool = False):
-    """-> (frames [n x (h,w,c) uint8], stds [n x (h,w,c) float64] | None, exposures ndarray)."""
+                           uniform_dn: bool = False, smooth: bool = False):
+    """-> (frames [n x (h,w,c) uint8], stds [n x (h,w,c) float64] | None, exposures ndarray).
+    smooth: the radiance is a low-frequency pattern + 1 % noise instead of independent per element, so that saturated and
+    under-exposed pixels form regions as in a photograph (thresholded frames are then NaN in whole areas)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     t = synthetic_exposures(n)
@@ -29,6 +31,12 @@ def synthetic_stack_device(seed: int, n: int, h: int, w: int, c: int = 3, device
             frames.append(torch.randint(0, 256, (h, w, c), generator=gen, device=device, dtype=torch.uint8))
     else:
         rad = torch.rand((h, w, c), generator=gen, device=device, dtype=torch.float64) * 4
+        if smooth:
+            yy = torch.arange(h, device=device, dtype=torch.float64).view(h, 1, 1) / h
+            xx = torch.arange(w, device=device, dtype=torch.float64).view(1, w, 1) / w
+            cc = 1.0 + 0.1 * torch.arange(c, device=device, dtype=torch.float64).view(1, 1, c)
+            rad = (2.0 + 1.9 * torch.sin(6.283185307179586 * 3 * xx) * torch.cos(6.283185307179586 * 2 * yy)) * cc / 1.2 + 0.01 * rad
+            rad = torch.clamp(rad, 0.0, 4.0)
         k = 255 / (4 * t[n // 2])
         for ti in t:
             frames.append(torch.clamp(torch.round(rad * float(ti * k)), 0, 255).to(torch.uint8))

@@ -508,3 +508,44 @@ def test_pair_statistics_zero_and_infinite_operands(with_std):
                 np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-12)
                 assert np.array_equal(np.isnan(allp), np.isnan(ref)) and np.array_equal(np.isinf(allp), np.isinf(ref)), (key, allp, ref)
                 np.testing.assert_allclose(allp[fin], ref[fin], rtol=1e-12)      # the all-pairs kernel (another partition of the elements)
+
+
+@pytest.mark.parametrize("with_std", [True, False])
+def test_pair_statistics_nan_regions(with_std):
+    """Thresholded frames are NaN in whole regions. The pair kernels decide per 64-element chunk and wave whether it is entirely NaN
+    (skipped), entirely valid (select-free update) or mixed (general update); all three must give what NumPy's nan-functions give.
+    An image whose FIRST rows are NaN (lanes meet valid data late: no shift K yet), with NaN blocks, isolated NaNs, a NaN only in the
+    value (its std valid: the weight still counts, measurand.py:342-347) and a NaN only in the std, against the oracle."""
+    from camera_linearity_amd import engine
+    rng = np.random.default_rng(11)
+    h, w = 96, 128
+    x = 0.2 + rng.random((h, w, 3))
+    y = 0.3 + rng.random((h, w, 3))
+    sx = 0.01 + 0.01 * rng.random((h, w, 3))
+    sy = 0.01 + 0.01 * rng.random((h, w, 3))
+    for a_ in (x, sx):
+        a_[:7] = np.nan                                  # the image starts with NaN rows
+        a_[40:60, 30:90] = np.nan                        # a block
+    y[70:80] = np.nan
+    sy[70:80] = np.nan
+    iso = rng.random((h, w, 3)) < 0.01
+    x[iso] = np.nan
+    sx[iso] = np.nan
+    x[20, 5:9] = np.nan                                  # value NaN, std valid
+    sy[25, 5:9] = np.nan                                 # std NaN, value valid
+    mult = 0.61
+    up = lambda a: torch.as_tensor(a, device="cuda")   # noqa: E731
+    args = (up(x), up(sx) if with_std else None, up(y), up(sy) if with_std else None, mult)
+    fa, fr = engine.pair_statistics(*args)
+    both = engine.pairs_statistics([args[0], args[2]], [args[1], args[3]] if with_std else None, [(0, 1, mult)])
+    three = engine.pairs_statistics([args[0], args[2], args[0]], [args[1], args[3], args[1]] if with_std else None,
+                                    [(0, 1, mult), (2, 1, mult), (0, 2, 1.0)])           # three frames: the LDS-staged kernel
+    ad, ads, rd, rds = orc.compute_difference(x, sx if with_std else None, y, sy if with_std else None, mult)
+    for got, p1, p3, dv, ds in ((fa, both[0][0], three[0][0], ad, ads), (fr, both[0][1], three[0][1], rd, rds)):
+        ref = orc.dimension_statistics(dv, ds, (0, 1))
+        for key in ("mean", "std", "error"):
+            if ref[key] is None:
+                assert got[key] is None
+                continue
+            for g_ in (got, p1, p3):
+                np.testing.assert_allclose(g_[key].cpu().numpy(), ref[key], rtol=1e-11)
