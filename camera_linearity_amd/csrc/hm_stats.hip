@@ -462,15 +462,22 @@ __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ 
 // v_rsq_f64, about 26 bits; already the IEEE answer for 0, infinities and NaN) and two Newton steps, kept only when the estimate is a
 // finite non-zero number - 7 / 10 instructions instead of 11 (divide) / ~26 (sqrt + divide).
 __device__ __forceinline__ bool finite_nonzero(double x) { const double ax = fabs(x); return ax > 0.0 && ax < __builtin_huge_val(); }
+template <int STEPS = 2>
 __device__ __forceinline__ double rcp_newton(double x, double r0) {
     const double r = fma(fma(-x, r0, 1.0), r0, r0);
+    if constexpr (STEPS == 1) return r;
     return fma(fma(-x, r, 1.0), r, r);
 }
+template <int STEPS = 2>
 __device__ __forceinline__ double rsq_newton(double q, double y0) {
     const double h = 0.5 * q;
     const double y = y0 * fma(-h * y0, y0, 1.5);
+    if constexpr (STEPS == 1) return y;
     return y * fma(-h * y, y, 1.5);
 }
+#ifndef HM_PAIR_NEWTON
+#define HM_PAIR_NEWTON 2
+#endif
 __device__ __forceinline__ double rcp_nr(double x) {
     const double r0 = __builtin_amdgcn_rcp(x);
     const double r = rcp_newton(x, r0);
@@ -501,7 +508,7 @@ __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, doub
     if constexpr (GUARD) inv = rcp_nr(scale);
     else {
         const double r0 = __builtin_amdgcn_rcp(scale);
-        inv = rcp_newton(scale, r0);
+        inv = rcp_newton<HM_PAIR_NEWTON>(scale, r0);
         special = __builtin_amdgcn_class(r0, kClassZeroInf);
     }
     r = a * inv;                                        // :636
@@ -517,8 +524,8 @@ __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, doub
             wr = rsqrt_nr(qr, rs);
         } else {
             const double ya0 = __builtin_amdgcn_rsq(qa), yr0 = __builtin_amdgcn_rsq(qr);
-            wa = rsq_newton(qa, ya0); as = qa * wa;
-            wr = rsq_newton(qr, yr0); rs = qr * wr;
+            wa = rsq_newton<HM_PAIR_NEWTON>(qa, ya0); as = qa * wa;
+            wr = rsq_newton<HM_PAIR_NEWTON>(qr, yr0); rs = qr * wr;
             special = special || __builtin_amdgcn_class(ya0, kClassZeroInf) || __builtin_amdgcn_class(yr0, kClassZeroInf);
         }
     }
