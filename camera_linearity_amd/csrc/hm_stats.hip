@@ -432,13 +432,14 @@ __device__ __forceinline__ Mom stats_loop(const double* val, const double* sd, i
     return acc_finish<false>(st, WEIGHTED);
 }
 
+template <bool WEIGHTED>          // one kernel per case: each gets the registers (occupancy) and the code size of its own loop
 __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ val, const double* __restrict__ sd, int64_t n, int C,
                                                double* __restrict__ partial) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
     const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     const int ct = static_cast<int>((sb0 + lane) % C);
-    const Mom mine[1] = {sd ? stats_loop<true>(val, sd, n, sb0, stride, lane) : stats_loop<false>(val, sd, n, sb0, stride, lane)};
+    const Mom mine[1] = {stats_loop<WEIGHTED>(val, sd, n, sb0, stride, lane)};
     block_merge_store<1>(mine, ct, partial);
 }
 
@@ -617,6 +618,7 @@ __device__ __forceinline__ void pair_loop(const double* x, const double* sx, con
     pair_tail<SX, SY>(st, it, sb, x, sx, y, sy, mult, n, stride, lane, mine);
 }
 
+template <bool SX, bool SY>
 __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x, const double* __restrict__ sx,
                                                     const double* __restrict__ y, const double* __restrict__ sy, double mult,
                                                     int64_t n, int C, double* __restrict__ partial) {
@@ -625,10 +627,7 @@ __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x
     const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     const int ct = static_cast<int>((sb0 + lane) % C);
     Mom mine[2];
-    if (sx && sy) pair_loop<true, true, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
-    else if (sx) pair_loop<true, false, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
-    else if (sy) pair_loop<false, true, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
-    else pair_loop<false, false, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
+    pair_loop<SX, SY, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
     block_merge_store<2>(mine, ct, partial);
 }
 
@@ -981,7 +980,8 @@ extern "C" int hm_channel_statistics(const double* val, const double* std, int64
     double* partial = static_cast<double*>(workspace);
     const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, val, std, n, C, partial);
+    if (std) hipLaunchKernelGGL(k_stats<true>, dim3(grid), dim3(256), 0, st, val, std, n, C, partial);
+    else hipLaunchKernelGGL(k_stats<false>, dim3(grid), dim3(256), 0, st, val, std, n, C, partial);
     hipLaunchKernelGGL(k_stats_final, dim3(C), dim3(256), 0, st, partial, grid, C, std ? 1 : 0, out);
     return launch_status();
 }
@@ -996,7 +996,9 @@ extern "C" int hm_pair_statistics(const double* x, const double* sx, const doubl
     double* partial = static_cast<double*>(workspace);
     const int grid = stat_grid(n);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(k_pair_stats, dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, partial);
+#define HM_PAIR(A, B) hipLaunchKernelGGL((k_pair_stats<A, B>), dim3(grid), dim3(256), 0, st, x, sx, y, sy, multiplier, n, C, partial)
+    if (sx && sy) HM_PAIR(true, true); else if (sx) HM_PAIR(true, false); else if (sy) HM_PAIR(false, true); else HM_PAIR(false, false);
+#undef HM_PAIR
     hipLaunchKernelGGL(k_pair_final, dim3(2 * C), dim3(256), 0, st, partial, grid, C, (sx || sy) ? 1 : 0, out);
     return launch_status();
 }
