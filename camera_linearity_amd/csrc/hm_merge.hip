@@ -1481,6 +1481,7 @@ constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{2,
 static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
     c = val3_default(n_frames);
     if (variant == 0) return true;
+    variant %= 10000;                                     // (tuning builds: W * 10000 + 7UPM also sets the workgroups per CU, launch_val3_cfg)
     if (variant < 7000 || variant >= 8000 || n_frames != HM_TUNE_NF) return false;
     c.u = (variant / 100) % 10; c.pf = (variant / 10) % 10; c.map = variant % 10;
     return c.u >= 1 && c.u <= 3 && c.pf <= 1 && c.map <= 1;
@@ -1500,10 +1501,16 @@ static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map ? 4 : 1) * st
 template <int NF, int U, int PF, int MAP>
 static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
     const int64_t units = k.n_elems / (U * (MAP ? 4 : 1) * static_cast<int>(kSub));
+    // workgroups per CU (8 are resident). U = 2 (N <= 8): 12 - a grid of 3072 is a multiple of 3 as it stands (2048 had to become 2046) and
+    // config 2's 196 608 units divide evenly among its waves; same-process A/B with shared output buffers (tools/ab_val3.py, variants
+    // W * 10000 + 7210 of a tuning build, profiles/r02h_ab_val3_wg_per_cu.log): 134.9 against 136.7 us (8) on a slow box, 129.0 against 129.9 us
+    // on a fast one; 2, 3, 4, 6, 16, 24, 32 are no better. U = 3 keeps 8 (config 4's tile: 65 536 units = 8 per wave).
 #ifndef HM_VAL3_WG_PER_CU
-#define HM_VAL3_WG_PER_CU 8
+#define HM_VAL3_WG_PER_CU (U % 3 != 0 ? 12 : 8)
 #endif
-    unsigned grid = MAP ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, HM_VAL3_WG_PER_CU);   // 8 workgroups of 4 waves per CU
+    int wg_per_cu = HM_VAL3_WG_PER_CU;
+    if (HM_TUNE_NF != 0 && k.variant >= 10000) wg_per_cu = k.variant / 10000;
+    unsigned grid = MAP ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, wg_per_cu);   // 8 workgroups of 4 waves per CU
     if (U % 3 != 0 && grid >= 3) grid -= grid % 3;          // the unit index must advance by a multiple of 3 per iteration (see the kernel)
     if (grid == 0) grid = 1;
     if (describe_only("merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;
@@ -1806,10 +1813,11 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
 
     // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
-    if (g->variant >= 7000 && g->variant < 9000) {            // merge_u8_val3 / merge_u8_priv A/B variants (tuning builds)
+    const int tune_variant = (HM_TUNE_NF != 0 && g->variant >= 10000) ? g->variant % 10000 : g->variant;   // W * 10000 + 7UPM (tuning builds)
+    if (tune_variant >= 7000 && tune_variant < 9000) {        // merge_u8_val3 / merge_u8_priv A/B variants (tuning builds)
         Val3Cfg vc;
         int pu = 0;
-        const bool ok = g->variant < 8000 ? val3_variant(g->variant, N, vc) : priv_variant(g->variant, N, pu);
+        const bool ok = tune_variant < 8000 ? val3_variant(g->variant, N, vc) : priv_variant(g->variant, N, pu);
         if (!ok || with_std || flat || g->out_sum_w || f64in || C != 3) return HM_EINVAL;
         cfg = default_cfg(with_std);
     } else if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
