@@ -56,7 +56,30 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, int
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
 }
+// One dword per thread and pass from a different `stride`-sized page each time: with many more pages than TLB entries the pass time is
+// the address-translation cost of the buffer's physical backing (fragment size), not its bandwidth (tools/tlb_probe.py).
+__global__ __launch_bounds__(256) void k_stride_probe(const uint32_t* __restrict__ p, uint64_t n_pages, uint64_t stride_dw, int passes,
+                                                      uint32_t* __restrict__ sink) {
+    const uint64_t tid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uint64_t in_page = stride_dw < 1024 ? stride_dw : 1024;                      // stay inside the first 4 KB of a page
+    uint32_t acc = 0;
+    for (int q = 0; q < passes; ++q) {
+        const uint64_t page = (tid * 7u + static_cast<uint64_t>(q) * nthreads * 7u + static_cast<uint64_t>(q) * 131u) % n_pages;
+        const uint64_t off = page * stride_dw + (static_cast<uint64_t>(q) * 16u) % in_page;
+        acc += __builtin_nontemporal_load(p + off);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;                                             // keeps the loads alive
+}
 }  // namespace hm
+
+extern "C" int hm_debug_stride_probe(const void* buf, unsigned long long bytes, unsigned long long stride_bytes, int passes, int blocks,
+                                     unsigned int* sink_device, void* stream) {
+    if (!buf || !sink_device || stride_bytes < 64 || (stride_bytes & 3) || bytes < stride_bytes || passes < 1 || blocks < 1) return HM_EINVAL;
+    hipLaunchKernelGGL(hm::k_stride_probe, dim3(blocks), dim3(256), 0, hm::as_stream(stream), static_cast<const uint32_t*>(buf),
+                       bytes / stride_bytes, stride_bytes / 4, passes, sink_device);
+    return hm::launch_status();
+}
 
 extern "C" int hm_debug_clock_probe(unsigned long long* out_device /*2 x uint64*/, int spins, void* stream) {
     if (!out_device || spins < 1) return HM_EINVAL;
