@@ -549,3 +549,51 @@ def test_pair_statistics_nan_regions(with_std):
                 continue
             for g_ in (got, p1, p3):
                 np.testing.assert_allclose(g_[key].cpu().numpy(), ref[key], rtol=1e-11)
+
+
+@pytest.mark.parametrize("offset,n", [(0, 4099), (0, 4096), (1, 4097), (1, 4098)])
+def test_dense_and_general_kernel_paths_agree(offset, n):
+    """hm_binary_op, hm_compute_difference, hm_channel_statistics and hm_pair_statistics pick a two-elements-per-lane kernel for dense,
+    16-byte-aligned operands and a general one otherwise. Views that start one float64 into an allocation (8-byte aligned only) and odd
+    lengths take the other paths; every path must give NumPy's result (the reference's formulas, measurand.py:106-241, :620-655)."""
+    from camera_linearity_amd import engine, _native as nat
+    rng = np.random.default_rng(offset * 10 + n)
+    host = {k: rng.random(n + 2) + 0.5 for k in ("x", "y")}
+    host.update({k: 0.01 + 0.02 * rng.random(n + 2) for k in ("sx", "sy")})
+    dev = {k: torch.as_tensor(v, device="cuda")[offset:offset + n] for k, v in host.items()}
+    h = {k: v[offset:offset + n] for k, v in host.items()}
+    assert all((t_.data_ptr() % 16 == 0) == (offset == 0) for t_ in dev.values())
+    x, y, sx, sy = h["x"], h["y"], h["sx"], h["sy"]
+    want = {
+        nat.HM_OP_ADD: (x + y, np.sqrt(sx ** 2 + sy ** 2)),
+        nat.HM_OP_SUB: (x - y, np.sqrt(sx ** 2 + sy ** 2)),
+        nat.HM_OP_MUL: (x * y, np.sqrt((x * sy) ** 2 + (y * sx) ** 2)),
+        nat.HM_OP_DIV: (x / y, np.sqrt((sx / y) ** 2 + (x * sy / y ** 2) ** 2)),
+    }
+    for op, (wv, ws) in want.items():
+        v, s = engine.elementwise_binary(op, dev["x"], dev["sx"], dev["y"], dev["sy"])
+        np.testing.assert_allclose(v.cpu().numpy(), wv, rtol=1e-15)
+        np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=1e-14)
+        v, s = engine.elementwise_binary(op, dev["x"], None, dev["y"], dev["sy"])          # one std missing -> zeros (:121-124)
+        w0 = {nat.HM_OP_ADD: sy, nat.HM_OP_SUB: sy, nat.HM_OP_MUL: np.abs(x * sy), nat.HM_OP_DIV: np.abs(x * sy / y ** 2)}[op]
+        np.testing.assert_allclose(s.cpu().numpy(), w0, rtol=1e-14)
+        v, s = engine.elementwise_binary(op, dev["x"], None, dev["y"], None)
+        assert s is None
+        np.testing.assert_allclose(v.cpu().numpy(), wv, rtol=1e-15)
+    mult = 0.7
+    ad, ads, rd, rds = engine.compute_difference(dev["x"], dev["sx"], dev["y"], dev["sy"], mult)
+    oad, oads, ord_, ords = orc.compute_difference(x, sx, y, sy, mult)
+    for got, ref in ((ad, oad), (ads, oads), (rd, ord_), (rds, ords)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-14)
+    # statistics on (n // 3, 3) views: channel and pair kernels on the same unaligned / odd data
+    m = (n // 3) * 3
+    as3 = lambda t_: t_[:m].reshape(-1, 3)     # noqa: E731
+    fa, fr = engine.pair_statistics(as3(dev["x"]), as3(dev["sx"]), as3(dev["y"]), as3(dev["sy"]), mult)
+    for got, dv, ds in ((fa, oad, oads), (fr, ord_, ords)):
+        ref = orc.dimension_statistics(dv[:m].reshape(-1, 3), ds[:m].reshape(-1, 3), (0,))
+        for key in ("mean", "std", "error"):
+            np.testing.assert_allclose(got[key].cpu().numpy(), ref[key], rtol=1e-12)
+    st = engine.channel_statistics(as3(dev["x"]), as3(dev["sx"]))
+    ref = orc.dimension_statistics(x[:m].reshape(-1, 3), sx[:m].reshape(-1, 3), (0,))
+    for key in ("mean", "std", "error"):
+        np.testing.assert_allclose(st[key].cpu().numpy(), ref[key], rtol=1e-12)
