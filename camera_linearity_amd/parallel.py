@@ -130,43 +130,69 @@ class RowTileSet:
     def algorithmic_bytes(self) -> int:
         return sum(self.plans[t].algorithmic_bytes for t in self.mine)
 
-    def download(self):
-        """{tile: (val, std | None)} as pinned host tensors; the merges must have been launched on the current stream."""
-        if not self.mine:                                   # more ranks than tiles: nothing to bring back
-            return {}
-        dev = self.plans[self.mine[0]].device
+    def _side_stream(self, dev):
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(dev)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         self._copy_stream.wait_event(ev)
-        with torch.cuda.stream(self._copy_stream):
+        return self._copy_stream
+
+    def download(self, into=None):
+        """{tile: (val, std | None)} as pinned host tensors; the merges must have been launched on the current stream.
+        `into` = (val image, std image | None): pinned whole-image tensors whose rows receive the tiles directly (no per-tile buffers)."""
+        if not self.mine:                                   # more ranks than tiles: nothing to bring back
+            return {}
+        dev = self.plans[self.mine[0]].device
+        side = self._side_stream(dev)
+        out = {}
+        with torch.cuda.stream(side):
             for t in self.mine:
                 o = self.plans[t].outputs
-                if t not in self._host:
-                    self._host[t] = (torch.empty(o["val"].shape, dtype=torch.float64).pin_memory(),
-                                     torch.empty(o["std"].shape, dtype=torch.float64).pin_memory() if "std" in o else None)
-                hv, hs = self._host[t]
+                if into is not None:
+                    r0, r1 = self.bounds[t]
+                    hv = into[0][r0:r1]
+                    hs = into[1][r0:r1] if (into[1] is not None and "std" in o) else None
+                else:
+                    if t not in self._host:                 # (pinned at creation: .pin_memory() on a pageable tensor allocates and copies it)
+                        self._host[t] = (torch.empty(o["val"].shape, dtype=torch.float64, pin_memory=True),
+                                         torch.empty(o["std"].shape, dtype=torch.float64, pin_memory=True) if "std" in o else None)
+                    hv, hs = self._host[t]
                 hv.copy_(o["val"], non_blocking=True)
                 if hs is not None:
                     hs.copy_(o["std"], non_blocking=True)
-        self._copy_stream.synchronize()
-        return {t: self._host[t] for t in self.mine}
+                out[t] = (hv, hs)
+        side.synchronize()
+        return out
 
     def assemble(self, group=None, dst: int = 0):
-        """(val, std) of the whole image as host tensors on `dst`, (None, None) elsewhere."""
-        local = self.download()
-        return gather_tiles(local, self.bounds, group=group, dst=dst, world_size=self.world, rank=self.rank)
+        """(val, std) of the whole image as host tensors on `dst`, (None, None) elsewhere. The destination rank's own tiles go from the
+        device straight into their rows of the (pinned) image; the other ranks' tiles arrive over the CPU group into theirs."""
+        image = None
+        if self.rank == dst and self.mine:
+            o = self.plans[self.mine[0]].outputs
+            tail = tuple(o["val"].shape[1:])
+            key = (self.height,) + tail + ("std" in o,)
+            if getattr(self, "_image_key", None) != key:
+                self._image = (torch.empty((self.height,) + tail, dtype=torch.float64, pin_memory=True),
+                               torch.empty((self.height,) + tail, dtype=torch.float64, pin_memory=True) if "std" in o else None)
+                self._image_key = key
+            image = self._image
+        local = self.download(into=image)
+        return gather_tiles(local, self.bounds, group=group, dst=dst, world_size=self.world, rank=self.rank, image=image)
 
 
-def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst: int = 0, world_size: int = 1, rank: int = 0):
+def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst: int = 0, world_size: int = 1, rank: int = 0, image=None):
     """Assemble {tile index: (val, std | None)} dictionaries of all ranks into one image on `dst`. With one rank this is a
     concatenation into a preallocated buffer; with several, every tile travels as ONE tensor send / receive over the CPU
-    (gloo) group straight into its rows of the destination image."""
+    (gloo) group straight into its rows of the destination image. `image` = (val, std | None) preallocated on `dst` whose rows already
+    hold dst's own tiles (RowTileSet.assemble): those are not copied again."""
     some = next(iter(local.values())) if local else None
     with_std = some is not None and some[1] is not None
     if world_size == 1:
         shape_tail = tuple(some[0].shape[1:])
+        if image is not None:
+            return image[0], (image[1] if with_std else None)
         H = bounds[-1][1]
         val = torch.empty((H,) + shape_tail, dtype=torch.float64)
         std = torch.empty((H,) + shape_tail, dtype=torch.float64) if with_std else None
@@ -186,8 +212,11 @@ def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst
     val = std = None
     if rank == dst:
         H = bounds[-1][1]
-        val = torch.empty((H, W, Cc), dtype=torch.float64)
-        std = torch.empty((H, W, Cc), dtype=torch.float64) if with_std else None
+        if image is not None:
+            val, std = image[0], (image[1] if with_std else None)
+        else:
+            val = torch.empty((H, W, Cc), dtype=torch.float64)
+            std = torch.empty((H, W, Cc), dtype=torch.float64) if with_std else None
     reqs = []
     for t in range(n_tiles):
         owner = t % world_size
@@ -195,7 +224,7 @@ def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst
         if r1 == r0:
             continue
         if owner == dst:
-            if rank == dst:
+            if rank == dst and image is None:
                 val[r0:r1] = torch.as_tensor(local[t][0])
                 if with_std:
                     std[r0:r1] = torch.as_tensor(local[t][1])
