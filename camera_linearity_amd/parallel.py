@@ -44,8 +44,7 @@ def tiles_for_rank(n_tiles: int, rank: int, world_size: int) -> List[int]:
 
 
 def _pinned_like(a: np.ndarray) -> torch.Tensor:
-    t = torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype)
-    return t.pin_memory() if torch.cuda.is_available() else t
+    return torch.empty(a.shape, dtype=torch.from_numpy(a[:0]).dtype, pin_memory=torch.cuda.is_available())
 
 
 def merge_row_tile(frames_host: Sequence[np.ndarray], exposures, icrf, icrf_diff=None, stds_host=None,
@@ -84,11 +83,11 @@ def merge_row_tile(frames_host: Sequence[np.ndarray], exposures, icrf, icrf_diff
             kw.update(flat_std=up(flat_std_host, r0, r1), ff_std_mean=ff_std_mean)
     out = engine.merge(frames, exposures, icrf, icrf_diff, stds, darks=darks, dark_min=dark_min, median_k=median_k,
                        height=H, row0=r0, rows=r1 - r0, buf_row0=b0, **kw)
-    h_val = torch.empty(out["val"].shape, dtype=torch.float64).pin_memory()
+    h_val = torch.empty(out["val"].shape, dtype=torch.float64, pin_memory=True)
     h_val.copy_(out["val"], non_blocking=True)
     h_std = None
     if "std" in out:
-        h_std = torch.empty(out["std"].shape, dtype=torch.float64).pin_memory()
+        h_std = torch.empty(out["std"].shape, dtype=torch.float64, pin_memory=True)
         h_std.copy_(out["std"], non_blocking=True)
     torch.cuda.current_stream(device).synchronize()
     return r0, r1, h_val.numpy(), (None if h_std is None else h_std.numpy())

@@ -42,13 +42,13 @@ class MergePipeline:
         self.slots = []
         for _ in range(depth):
             s = _Slot()
-            s.h_frames = [torch.empty(self.shape, dtype=torch.uint8).pin_memory() for _ in range(n_frames)]
-            s.h_stds = [torch.empty(self.shape, dtype=torch.float64).pin_memory() for _ in range(n_frames)] if with_std else None
+            s.h_frames = [torch.empty(self.shape, dtype=torch.uint8, pin_memory=True) for _ in range(n_frames)]
+            s.h_stds = [torch.empty(self.shape, dtype=torch.float64, pin_memory=True) for _ in range(n_frames)] if with_std else None
             s.d_frames = [torch.empty(self.shape, dtype=torch.uint8, device=self.device) for _ in range(n_frames)]
             s.d_stds = [torch.empty(self.shape, dtype=torch.float64, device=self.device) for _ in range(n_frames)] if with_std else None
             s.plan = engine.plan_merge(s.d_frames, exposures, icrf, icrf_diff if with_std else None, s.d_stds)
-            s.h_val = torch.empty(self.shape, dtype=torch.float64).pin_memory()
-            s.h_std = torch.empty(self.shape, dtype=torch.float64).pin_memory() if with_std else None
+            s.h_val = torch.empty(self.shape, dtype=torch.float64, pin_memory=True)
+            s.h_std = torch.empty(self.shape, dtype=torch.float64, pin_memory=True) if with_std else None
             s.ev_h2d = torch.cuda.Event()
             s.ev_run = torch.cuda.Event()
             s.ev_d2h = torch.cuda.Event()
