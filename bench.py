@@ -15,7 +15,7 @@ measured with HIP events on the launch stream inside the timed region; the cpu_b
 (a port of the reference's merge arithmetic) on a bounded row band of the same stack on the host, rank 0, N = 1 only,
 and checks the GPU output of the timed configuration against it.
 Other workloads (--workload): cfg3* = configs[2] and its parts, cfg4 / cfg4std = configs[3] (ONE 15 x 8192 x 8192 x 3 image
-in 8 row tiles dealt to the ranks, host-side assembly), cfg5 = configs[4], cfg2rand, cfg2f64 / cfg3f64std, welford, energy.
+in 8 row tiles dealt to the ranks, host-side assembly), cfg5 = configs[4], cfg2rand, cfg2smooth, cfg2f64 / cfg3f64std, welford, energy.
 """
 import argparse
 import json
@@ -43,6 +43,7 @@ WORKLOADS = {
     "cfg4tilestd": (15, 1024, 8192, True, False),  # configs[3] "+std" variant of the same tile
     "cfg5": (7, 4096, 4096, False, False),      # configs[4]: 64 independent config-2 stacks on 8 GPUs = 8 resident stacks per GPU, one step merges all 8
     "cfg2rand": (7, 4096, 4096, False, False),  # config 2 with uniform-random DNs: the worst case for LDS bank conflicts
+    "cfg2smooth": (7, 4096, 4096, False, False),  # config 2 on a photograph-like radiance (low-frequency pattern + 1 % noise): neighbouring lanes gather neighbouring table rows
     "cfg2f64": (7, 4096, 4096, False, False),   # 64-bit mode (image_set.py:225): float64 frames, analytic weights, computed index
     "cfg3f64std": (7, 4096, 4096, True, False),  # 64-bit mode with std
 }
@@ -363,12 +364,12 @@ def main():
         return
     n, H, W, with_std, corr = WORKLOADS[a.workload]
     icrf, diff = synthetic_icrf()
-    rotate = a.stacks if a.stacks > 0 else (4 if a.workload in ("cfg2", "cfg2rand") else 1)
+    rotate = a.stacks if a.stacks > 0 else (4 if a.workload in ("cfg2", "cfg2rand", "cfg2smooth") else 1)
     if a.workload == "cfg5":
         rotate = 1
 
     def build_stack(seed):
-        frames, stds, t = synthetic_stack_device(seed, n, H, W, device=dev, with_std=with_std)
+        frames, stds, t = synthetic_stack_device(seed, n, H, W, device=dev, with_std=with_std, smooth=a.workload == "cfg2smooth")
         if "f64" in a.workload:
             frames = [engine.u8_to_unit(f) for f in frames]
         if a.workload == "cfg2rand":
