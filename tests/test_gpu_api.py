@@ -597,3 +597,45 @@ def test_dense_and_general_kernel_paths_agree(offset, n):
     ref = orc.dimension_statistics(x[:m].reshape(-1, 3), sx[:m].reshape(-1, 3), (0,))
     for key in ("mean", "std", "error"):
         np.testing.assert_allclose(st[key].cpu().numpy(), ref[key], rtol=1e-12)
+
+
+@pytest.mark.parametrize("with_std", [True, False])
+def test_pair_statistics_many_iterations(with_std):
+    """The whole-chunk loops of the statistics kernels (prefetching register sets in hm_pair_statistics, the three-stage LDS pipeline
+    with one barrier per iteration in hm_pairs_statistics) only run when an image has more than 2 x 768 x 64 elements; the small
+    parity cases end in their tail paths. 4 frames of 1024 x 1024 x 3 (+ 100 extra elements so that the tail runs too) with NaNs,
+    all 6 pairs: the all-pairs launch, the per-pair launches and NumPy's nan-functions (the oracle) must agree."""
+    from camera_linearity_amd import engine
+    rng = np.random.default_rng(3)
+    n_el = 1024 * 1024 + 100
+    shape = (n_el, 3)
+    vals = [0.2 + rng.random(shape) * (1.0 + 0.3 * i) for i in range(4)]
+    stds = [0.01 + 0.02 * rng.random(shape) for _ in range(4)]
+    for i, (v, s) in enumerate(zip(vals, stds)):
+        m = rng.random(shape) < 0.1
+        v[m] = np.nan
+        s[m] = np.nan
+        v[i * 1000:(i + 1) * 1000 + 5000] = np.nan            # a NaN run (rows of a thresholded image)
+        s[i * 1000:(i + 1) * 1000 + 5000] = np.nan
+    up = lambda a: torch.as_tensor(a, device="cuda")   # noqa: E731
+    gv = [up(v) for v in vals]
+    gs = [up(s) for s in stds] if with_std else None
+    pairs = [(i, j, 0.4 + 0.1 * (i + j)) for i in range(4) for j in range(i + 1, 4)]
+    allp = engine.pairs_statistics(gv, gs, pairs)
+    assert len(allp) == 6
+    for (i, j, m), got in zip(pairs, allp):
+        single = engine.pair_statistics(gv[i], gs[i] if with_std else None, gv[j], gs[j] if with_std else None, m)
+        ad, ads, rd, rds = orc.compute_difference(vals[i], stds[i] if with_std else None, vals[j], stds[j] if with_std else None, m)
+        for g_, s_, dv, ds in ((got[0], single[0], ad, ads), (got[1], single[1], rd, rds)):
+            ref = orc.dimension_statistics(dv, ds, (0,))
+            for key in ("mean", "std", "error"):
+                if ref[key] is None:
+                    assert g_[key] is None and s_[key] is None
+                    continue
+                np.testing.assert_allclose(g_[key].cpu().numpy(), ref[key], rtol=1e-11)
+                np.testing.assert_allclose(s_[key].cpu().numpy(), ref[key], rtol=1e-11)
+    # bit-reproducible
+    again = engine.pairs_statistics(gv, gs, pairs)
+    for a_, b_ in zip(allp, again):
+        for h in (0, 1):
+            assert torch.equal(a_[h]["mean"], b_[h]["mean"]) and torch.equal(a_[h]["std"], b_[h]["std"])
