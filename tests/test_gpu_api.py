@@ -639,3 +639,46 @@ def test_pair_statistics_many_iterations(with_std):
     for a_, b_ in zip(allp, again):
         for h in (0, 1):
             assert torch.equal(a_[h]["mean"], b_[h]["mean"]) and torch.equal(a_[h]["std"], b_[h]["std"])
+
+
+def test_per_frame_kernels_many_iterations():
+    """Linearization (the streaming kernel's register ping-pong loop needs more than 8192 groups of 384 elements per launch), thresholds and
+    the Gaussian weight on a 2048 x 2048 x 3 frame (+ a ragged tail), uint8 and float64 input, against the oracle: the small property
+    cases end in the kernels' tail / single-iteration paths."""
+    from camera_linearity_amd import engine
+    rng = np.random.default_rng(17)
+    n_pix = 2048 * 2048 + 37
+    dn = rng.integers(0, 256, (n_pix, 3), dtype=np.uint8)
+    sd = 0.004 * (1 + rng.random((n_pix, 3)))
+    icrf, diff = orc.synthetic_icrf()
+    g_dn, g_sd = torch.as_tensor(dn, device="cuda"), torch.as_tensor(sd, device="cuda")
+    # uint8 input with std, per-channel tables
+    v, s = engine.linearize(g_dn, g_sd, icrf, diff)
+    ov, os_, _ = orc.linearize(dn, sd, icrf, diff)
+    assert np.array_equal(v.cpu().numpy(), ov)
+    np.testing.assert_allclose(s.cpu().numpy(), os_, rtol=1e-15)
+    # float64 input (with .5 ties and values past 1.0), index returned
+    x = dn.astype(np.float64) / 255.0
+    x[::7] += 0.5 / 255.0
+    x[::11] += 1.0
+    v, s, idx = engine.linearize(torch.as_tensor(x, device="cuda"), g_sd, icrf, diff, return_index=True)
+    ov, os_, oidx = orc.linearize(x, sd, icrf, diff)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(v.cpu().numpy(), ov)
+    np.testing.assert_allclose(s.cpu().numpy(), os_, rtol=1e-15)
+    # thresholds in place
+    lo, hi = [0.1, 0.2, 0.3], [0.8, 0.7, 0.9]
+    tv, ts = torch.as_tensor(ov, device="cuda").clone(), torch.as_tensor(os_, device="cuda").clone()
+    engine.apply_thresholds_(tv, ts, lo, hi)
+    rv, rs = orc.apply_thresholds(ov, os_, lo, hi)
+    np.testing.assert_array_equal(tv.cpu().numpy(), rv)
+    np.testing.assert_array_equal(ts.cpu().numpy(), rs)
+    # Gaussian weight of the uint8 frame (LUT) and of the float64 frame (analytic)
+    w, dw = engine.gaussian_weight(g_dn)
+    ow, odw = orc.gaussian_weight(dn.astype(np.float64) / 255.0)
+    np.testing.assert_allclose(w.cpu().numpy(), ow, rtol=1e-15)
+    np.testing.assert_allclose(dw.cpu().numpy(), odw, rtol=1e-14, atol=1e-300)
+    w, dw = engine.gaussian_weight(torch.as_tensor(x, device="cuda"))
+    ow, odw = orc.gaussian_weight(x)
+    np.testing.assert_allclose(w.cpu().numpy(), ow, rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(dw.cpu().numpy(), odw, rtol=1e-13, atol=1e-300)
