@@ -772,3 +772,49 @@ def test_merge_tile_of_more_than_2_pow_32_elements(eng):
     r0 = 65530                                                               # the internal boundary is at row 65534
     ref = orc.merge([f[r0:].cpu().numpy() for f in frames], t, icrf)
     close(host(whole[r0:]), ref["val"], VAL_RTOL)
+
+
+def test_correction_kernels_on_a_large_frame(eng):
+    """Standalone hot-pixel filter, flat-field ROI mean, normalize_by_map and the Welford fold on a 1536 x 2048 x 3 frame: sizes at which
+    every grid-stride / chunked loop of these kernels iterates (the small cases above finish in one pass), against the oracle."""
+    rng = np.random.default_rng(29)
+    h, w = 1536, 2048
+    x = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    dark = rng.integers(0, 8, size=(h, w, 3)).astype(np.uint8)
+    dark[rng.random((h, w, 3)) < 1e-3] = 200
+    thr = 0.1
+    for k in (3, 5):
+        ref = orc.hot_pixel_filter(x.astype(np.float64), orc.unit_from_u8(dark), thr, k)
+        out = eng.hot_pixel_filter(dev(x), dev(dark), thr, k)
+        assert np.array_equal(host(out).astype(np.float64), ref)
+    xs = rng.random((h, w, 3))
+    refs = orc.hot_pixel_filter(xs, orc.unit_from_u8(dark), thr, 3)
+    outs = eng.hot_pixel_filter(dev(xs), dev(orc.unit_from_u8(dark)), thr, 3)
+    assert np.array_equal(host(outs), refs)
+    # flat field: ROI means and normalize_by_map
+    flat = np.clip(np.around(255 * (0.8 + 0.05 * rng.random((h, w, 3)))), 0, 255).astype(np.uint8)
+    fval = orc.unit_from_u8(flat)
+    fstd = 0.002 * (1 + rng.random((h, w, 3)))
+    x0, x1, y0, y1 = eng.flat_roi_bounds(h, w, 0.2)
+    m = host(eng.roi_mean(dev(flat), x0, x1, y0, y1))
+    s = host(eng.roi_mean(dev(fstd), x0, x1, y0, y1))
+    # NumPy's mean over axes (0, 1) of a (rows, cols, 3) slice accumulates ~1e5 terms per channel naively: the oracle is only good to
+    # ~1e-12 here. Against long-double sums the kernel's tree reduction holds 1e-15 (uint8: the DN sum is exact in float64).
+    close(m, orc.flat_roi_mean(fval, h, w, 0.2), 5e-12)
+    close(s, orc.flat_roi_mean(fstd, h, w, 0.2), 5e-12)
+    exact = lambda a: np.asarray(a[x0:x1, y0:y1, :].astype(np.longdouble).sum(axis=(0, 1)) / ((x1 - x0) * (y1 - y0)), dtype=np.float64)   # noqa: E731
+    close(m, exact(flat.astype(np.longdouble) / np.longdouble(255)), 2e-15)
+    close(s, exact(fstd), 2e-15)
+    val, std = rng.random((h, w, 3)) + 0.1, 0.01 * (1 + rng.random((h, w, 3)))
+    nv, ns = eng.normalize_by_map(dev(val), dev(std), dev(flat), dev(fstd), m, s)
+    rv, rs = orc.normalize_by_map(val, std, fval, fstd, m, s)
+    close(host(nv), rv, 1e-14)
+    close(host(ns), rs, 1e-9)
+    # Welford fold of 5 frames (one launch) and its finalisation
+    frames = [rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(5)]
+    mean = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    m2 = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    c = eng.welford_update([dev(f) for f in frames], 0, mean, m2)
+    om, om2, oc = orc.welford_state(frames)
+    assert c == oc == 5
+    assert np.array_equal(host(mean), om) and np.array_equal(host(m2), om2)
