@@ -462,6 +462,26 @@ def main():
         e1.record()
     torch.cuda.synchronize()
     kernel_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in per]
+    # the box's copy rate (the library's nontemporal 16-byte copy kernel between two output buffers, after the timed region): the merge's
+    # traffic is ~half reads, ~half writes, and a plain copy is what the memory system sustains for such a mix
+    copy_gbps = None
+    if rank == 0 and len(plans) > 1 and "val" in plans[0].outputs and "val" in plans[1].outputs:
+        from camera_linearity_amd import _native as nat
+        src, dst = plans[0].outputs["val"], plans[1].outputs["val"]
+        nbytes = src.numel() * 8
+        st_ = torch.cuda.current_stream(dev).cuda_stream
+        for _ in range(20):
+            nat.check(nat.lib.hm_debug_copy_probe(src.data_ptr(), dst.data_ptr(), nbytes, st_), "copy probe")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(100):
+            a_, b_ = (src, dst) if k % 2 == 0 else (dst, src)
+            nat.check(nat.lib.hm_debug_copy_probe(a_.data_ptr(), b_.data_ptr(), nbytes, st_), "copy probe")
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * nbytes / (e0.elapsed_time(e1) * 1e-3 / 100) / 1e9
+        plans[0].launch(); plans[1].launch()                      # restore the outputs the CPU leg will check
+        torch.cuda.synchronize()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -499,7 +519,9 @@ def main():
                          "avg_launch_us": round(avg_us, 2),
                          "same_stack_avg_launch_us": None if same_us is None else round(same_us, 2),
                          "same_stack_frac": None if same_us is None else round(alg_bytes / same_us / 1e3 / HBM_PEAK_GBPS, 4),
-                         "isolated_launch_us_min_median": [round(float(np.min(kernel_us)), 2), round(float(np.median(kernel_us)), 2)]},
+                         "isolated_launch_us_min_median": [round(float(np.min(kernel_us)), 2), round(float(np.median(kernel_us)), 2)],
+                         "copy_GBps": None if copy_gbps is None else round(copy_gbps, 1),
+                         "frac_of_copy": None if copy_gbps is None else round(achieved / copy_gbps, 4)},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "hm_strerror": (C.c_char_p, [C.c_int]),
     "hm_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "hm_debug_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "hm_debug_copy_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p]),
     "hm_debug_stride_probe": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "hm_gaussian_weight_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "hm_gaussian_weight_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -71,7 +71,22 @@ __global__ __launch_bounds__(256) void k_stride_probe(const uint32_t* __restrict
     }
     if (acc == 0x12345678u) sink[0] = acc;                                             // keeps the loads alive
 }
+// dst[i] = src[i] with 16-byte nontemporal accesses: the copy rate of the box (a 50 % read / 50 % write stream) is what the merge's
+// 47 % / 53 % traffic mix can be held against (bench.py: roofline.copy_GBps)
+__global__ __launch_bounds__(256) void k_copy_probe(const double* __restrict__ src, double* __restrict__ dst, int64_t n16) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n16; q += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src) + q), reinterpret_cast<f64x2*>(dst) + q);
+}
 }  // namespace hm
+
+extern "C" int hm_debug_copy_probe(const void* src, void* dst, unsigned long long bytes, void* stream) {
+    if (!src || !dst || bytes < 16 || (bytes & 15) || !hm::aligned(src, 16) || !hm::aligned(dst, 16)) return HM_EINVAL;
+    hipLaunchKernelGGL(hm::k_copy_probe, dim3(hm::stream_grid(static_cast<int64_t>(bytes / 16), 256, 8)), dim3(256), 0, hm::as_stream(stream),
+                       static_cast<const double*>(src), static_cast<double*>(dst), static_cast<int64_t>(bytes / 16));
+    return hm::launch_status();
+}
 
 extern "C" int hm_debug_stride_probe(const void* buf, unsigned long long bytes, unsigned long long stride_bytes, int passes, int blocks,
                                      unsigned int* sink_device, void* stream) {

@@ -53,6 +53,9 @@ int hm_device_info(int* n_devices, int* cu_count, int* lds_bytes, char* arch, in
 /* Diagnostic: one wave samples the shader-cycle counter and the 100 MHz real-time counter over `spins` sleep periods on `stream` (launch it on a
  * side stream while the kernels of interest run): out_device[0] = shader cycles, out_device[1] = 100 MHz ticks -> clock [GHz] = [0] / [1] / 10. */
 int hm_debug_clock_probe(unsigned long long* out_device, int spins, void* stream);
+/* Debug: dst[0 .. bytes) = src[0 .. bytes) with 16-byte nontemporal loads and stores (16-byte aligned, bytes a multiple of 16): the
+ * copy bandwidth of the box, against which bench.py holds the merge's read / write mix (roofline.copy_GBps). No reference counterpart. */
+int hm_debug_copy_probe(const void* src, void* dst, unsigned long long bytes, void* stream);
 /* Debug: `blocks` x 256 threads each read `passes` dwords, every one from a different `stride_bytes`-sized page of buf[0 .. bytes): the
  * launch time reflects the address-translation cost of the buffer's physical backing (tools/tlb_probe.py). No reference counterpart. */
 int hm_debug_stride_probe(const void* buf, unsigned long long bytes, unsigned long long stride_bytes, int passes, int blocks,

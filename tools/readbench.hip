@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256) void k_fill(double* o, int64_t n) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_copy(const double* in, double* o, int64_t n) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n / 2; q += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f64x2*>(in) + q), reinterpret_cast<f64x2*>(o) + q);
+}
+
 int main(int argc, char** argv) {
     const int64_t n = 4096ll * 4096 * 3;
     if (argc > 2) {            // readbench hold <read|fill> : keep one shape running for ~8 s (power / clock polling from outside)
@@ -74,18 +80,20 @@ int main(int argc, char** argv) {
         q.n = n;
         for (int s = 0; s < 4; ++s) { (void)hipMalloc(const_cast<double**>(&q.s[s]), n * 8); (void)hipMemset(const_cast<double*>(q.s[s]), 0, n * 8); }
         (void)hipMalloc(&q.out, 8192 * 256 * 8);
-        const bool fill = argv[2][0] == 'f';
+        const bool fill = argv[2][0] == 'f', copy = argv[2][0] == 'c';
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0);
-        const int reps = 120000;
+        const int reps = copy ? 60000 : 120000;
         for (int i = 0; i < reps; ++i) {
-            if (fill) hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, const_cast<double*>(q.s[i & 3]), n);
+            if (copy) hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, q.s[i & 1], const_cast<double*>(q.s[2 + (i & 1)]), n);
+            else if (fill) hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, const_cast<double*>(q.s[i & 3]), n);
             else hipLaunchKernelGGL((k<1, 1, true, 4>), dim3(1024), dim3(256), 0, 0, P{{q.s[i & 3], nullptr, nullptr, nullptr}, n, q.out});
         }
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("%s: %.1f us per 403 MB, %.2f TB/s over %.1f s\n", fill ? "fill" : "read", ms / reps * 1e3, n * 8.0 / (ms / reps * 1e-3) / 1e12, ms / 1e3);
+        printf("%s: %.1f us per launch, %.2f TB/s over %.1f s\n", copy ? "copy (403 MB in + 403 MB out)" : fill ? "fill (403 MB)" : "read (403 MB)", ms / reps * 1e3,
+               (copy ? 2 : 1) * n * 8.0 / (ms / reps * 1e-3) / 1e12, ms / 1e3);
         return 0;
     }
     P p{};
