@@ -70,9 +70,17 @@ def cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads):
 DARK_THR = 0.05                 # pixel threshold of the dark maps (settings.DARK_THRESHOLD)
 
 
-def measured_traffic(workload):
+def _kernel_key(name):
+    """('merge_u8_val3', (7, 4, 1, 0)) from either the demangled symbol rocprof prints or the library's own description."""
+    import re
+    m = re.search(r"(merge_\w+)\s*<([^>]*)>", name or "")
+    return (m.group(1), tuple(int(x) for x in re.findall(r"-?\d+", m.group(2)))) if m else None
+
+
+def measured_traffic(workload, kernel=None):
     """HBM bytes per launch from the PMC pass of THIS round's profile run (tools/profile.sh -> profiles/r02_pmc_traffic.json,
-    which records the commit and workload it was collected on); None when there is no such record for the workload."""
+    which records the commit, workload and kernel it was collected on); None when there is no such record for the workload or when
+    it was taken on another kernel than the one this run launches."""
     tp = ROOT / "profiles" / "r02_pmc_traffic.json"
     if not tp.exists():
         return None, None
@@ -82,6 +90,8 @@ def measured_traffic(workload):
         return None, None
     ent = rec.get(workload)
     if not ent:
+        return None, None
+    if kernel is not None and _kernel_key(ent.get("kernel")) != _kernel_key(kernel.split(" + ")[0]):
         return None, None
     return ent.get("hbm_bytes_per_launch"), f"profiles/r02_pmc_traffic.json ({ent.get('kernel', '?')} @ {ent.get('commit', '?')})"
 
@@ -498,7 +508,7 @@ def main():
 
     if rank == 0:
         achieved = alg_bytes / avg_us / 1e3          # GB/s
-        traffic, traffic_src = measured_traffic(a.workload)
+        traffic, traffic_src = measured_traffic(a.workload, plan.kernels)
         mpix = world * a.steps * launches_per_step * H * W / elapsed / 1e6
         line = {
             "metric": "HDR-merged Mpix/s (node)", "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world,

@@ -846,16 +846,18 @@ template <int NF, int U, int PF, int MAP>
 __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     __shared__ __attribute__((aligned(16))) char lds[16 * 768];
     __shared__ uint32_t s_bad[4];
-    constexpr uint32_t SLOT = MAP ? 4u * kSub : kSub;              // element distance between a wave's consecutive slots
+    constexpr bool DEFER = MAP == 2;                               // MAP 2: the element map of MAP 0, all U stores of a unit issued together at its end
+    constexpr bool WGMAP = MAP == 1;
+    constexpr uint32_t SLOT = WGMAP ? 4u * kSub : kSub;            // element distance between a wave's consecutive slots
     constexpr uint32_t UNIT = U * SLOT;                            // elements per unit (group: U*128, chunk: U*512)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane16 = lane * 16u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t wave_el = MAP ? wave * kSub : 0u;               // scalar: the wave's element offset inside a chunk
+    const uint32_t wave_el = WGMAP ? wave * kSub : 0u;             // scalar: the wave's element offset inside a chunk
     const uint32_t lane2 = lane * 2u + wave_el;                    // element (= byte) offset of the lane's first element inside the unit
     const uint32_t n_units = static_cast<uint32_t>(a.n_elems / UNIT);
-    const uint32_t ustride = MAP ? gridDim.x : gridDim.x * 4u;
-    uint32_t u = MAP ? blockIdx.x : blockIdx.x * 4u + wave;        // wave-uniform
+    const uint32_t ustride = WGMAP ? gridDim.x : gridDim.x * 4u;
+    uint32_t u = WGMAP ? blockIdx.x : blockIdx.x * 4u + wave;      // wave-uniform
 
     // R[i][s]: the two DNs of frame i, slot s (kept 16-bit: widening at the load would put a v_and - and a wait for the
     // load - right behind it)
@@ -904,6 +906,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
         constexpr bool REFILL = decltype(refill_tag)::value;
         const uint32_t next_off = (unit + ustride) * UNIT;                                   // scalar: byte offset of the next unit in every frame
         double* og = a.out_val + static_cast<int64_t>(unit) * UNIT + wave_el;                // scalar base of the wave's output in this unit
+        double held[DEFER ? U : 1][2];
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             double S[2], acc[2];
@@ -947,7 +950,13 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
             double v0, v1;
             if (fastdiv) { v0 = div_inrange(acc[0], S[0]); v1 = div_inrange(acc[1], S[1]); }
             else { v0 = acc[0] / S[0]; v1 = acc[1] / S[1]; }
-            store2(og + SLOT * s, lane16, v0, v1);
+            if constexpr (DEFER) { held[s][0] = v0; held[s][1] = v1; }
+            else store2(og + SLOT * s, lane16, v0, v1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (DEFER) {                      // U KB of contiguous output in U back-to-back store instructions
+#pragma unroll
+            for (int s = 0; s < U; ++s) store2(og + SLOT * s, lane16, held[s][0], held[s][1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1477,14 +1486,17 @@ struct Val3Cfg { int u, pf, map; };
 // against 130.0 us for merge_u8_fast and 133-135 us for the in-place refill (profiles/r02_ab_val3_matrix2.json); above that the second
 // register set costs occupancy (N = 15: 137 VGPRs) and the in-place refill with U = 3 wins (82 VGPRs; config-4 tile 105.0 us against
 // 109.3 us for both <2, 1> and merge_u8_fast, profiles/r02_ab_val3_n15.json).
-constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{2, 1, 0} : Val3Cfg{3, 0, 0}; }
+// Late round 2: U = 4 with the second register set (115 VGPRs at N = 7) beats U = 2 by 1.3-1.9 us on three boxes, fast and slow (same-process A/B,
+// shared outputs: 130.2 / 130.3 / 136.4 against 132.1 / 132.0 / 137.9 us, profiles/r02h_ab_val3_u4.log) - 512 contiguous bytes per frame and 4 KB of
+// output per wave iteration; U = 5, 6, 8 and issuing a unit's stores together at its end (MAP = 2) are slower.
+constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{4, 1, 0} : Val3Cfg{3, 0, 0}; }
 static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
     c = val3_default(n_frames);
     if (variant == 0) return true;
     variant %= 10000;                                     // (tuning builds: W * 10000 + 7UPM also sets the workgroups per CU, launch_val3_cfg)
     if (variant < 7000 || variant >= 8000 || n_frames != HM_TUNE_NF) return false;
     c.u = (variant / 100) % 10; c.pf = (variant / 10) % 10; c.map = variant % 10;
-    return c.u >= 1 && c.u <= 3 && c.pf <= 1 && c.map <= 1;
+    return c.u >= 1 && c.u <= 8 && c.pf <= 1 && c.map <= 2;
 }
 #if HM_TUNE_NF != 0
 #include "hm_merge_priv_launch.inc"
@@ -1496,11 +1508,11 @@ static bool use_val3(int variant, int n_frames, bool with_std, bool extras) {
     Val3Cfg c;
     return !with_std && !extras && val3_variant(variant, n_frames, c);
 }
-static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map ? 4 : 1) * static_cast<int>(kSub); }
+static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map == 1 ? 4 : 1) * static_cast<int>(kSub); }
 
 template <int NF, int U, int PF, int MAP>
 static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
-    const int64_t units = k.n_elems / (U * (MAP ? 4 : 1) * static_cast<int>(kSub));
+    const int64_t units = k.n_elems / (U * (MAP == 1 ? 4 : 1) * static_cast<int>(kSub));
     // workgroups per CU (8 are resident). U = 2 (N <= 8): 12 - a grid of 3072 is a multiple of 3 as it stands (2048 had to become 2046) and
     // config 2's 196 608 units divide evenly among its waves; same-process A/B with shared output buffers (tools/ab_val3.py, variants
     // W * 10000 + 7210 of a tuning build, profiles/r02h_ab_val3_wg_per_cu.log): 134.9 against 136.7 us (8) on a slow box, 129.0 against 129.9 us
@@ -1510,7 +1522,7 @@ static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
 #endif
     int wg_per_cu = HM_VAL3_WG_PER_CU;
     if (HM_TUNE_NF != 0 && k.variant >= 10000) wg_per_cu = k.variant / 10000;
-    unsigned grid = MAP ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, wg_per_cu);   // 8 workgroups of 4 waves per CU
+    unsigned grid = MAP == 1 ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, wg_per_cu);   // 8 workgroups of 4 waves per CU
     if (U % 3 != 0 && grid >= 3) grid -= grid % 3;          // the unit index must advance by a multiple of 3 per iteration (see the kernel)
     if (grid == 0) grid = 1;
     if (describe_only("merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;
@@ -1532,6 +1544,17 @@ static int launch_val3(const MergeK& k, hipStream_t st) {
             case 210: return launch_val3_cfg<NF, 2, 1, 0>(k, st);
             case 211: return launch_val3_cfg<NF, 2, 1, 1>(k, st);
             case 100: return launch_val3_cfg<NF, 1, 0, 0>(k, st);
+            case 212: return launch_val3_cfg<NF, 2, 1, 2>(k, st);
+            case 312: return launch_val3_cfg<NF, 3, 1, 2>(k, st);
+            case 412: return launch_val3_cfg<NF, 4, 1, 2>(k, st);
+            case 410: return launch_val3_cfg<NF, 4, 1, 0>(k, st);
+            case 402: return launch_val3_cfg<NF, 4, 0, 2>(k, st);
+            case 400: return launch_val3_cfg<NF, 4, 0, 0>(k, st);
+            case 510: return launch_val3_cfg<NF, 5, 1, 0>(k, st);
+            case 610: return launch_val3_cfg<NF, 6, 1, 0>(k, st);
+            case 810: return launch_val3_cfg<NF, 8, 1, 0>(k, st);
+            case 600: return launch_val3_cfg<NF, 6, 0, 0>(k, st);
+            case 800: return launch_val3_cfg<NF, 8, 0, 0>(k, st);
             default:  return launch_val3_cfg<NF, 1, 1, 0>(k, st);
         }
     } else {

@@ -73,8 +73,62 @@ __global__ __launch_bounds__(256) void k_copy(const double* in, double* o, int64
         __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f64x2*>(in) + q), reinterpret_cast<f64x2*>(o) + q);
 }
 
+// copy with B x 16 bytes per lane read before the B stores (a wave moves B KB in, then B KB out), nontemporal or plain
+template <int B, bool NT>
+__global__ __launch_bounds__(256) void k_copy_b(const double* in, double* o, int64_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t chunk = 128ll * B;                                   // doubles per wave iteration
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * chunk;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4 * chunk;
+    for (int64_t b = wave0; b + chunk <= n; b += stride) {
+        f64x2 v[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const f64x2* p = reinterpret_cast<const f64x2*>(in + b + 128 * k) + lane;
+            v[k] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            f64x2* p = reinterpret_cast<f64x2*>(o + b + 128 * k) + lane;
+            if (NT) __builtin_nontemporal_store(v[k], p); else *p = v[k];
+        }
+    }
+}
+template <int B, bool NT>
+static void run_copy(const double* in, double* out, int64_t n, int grid, const char* name) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_copy_b<B, NT>), dim3(grid), dim3(256), 0, 0, in, out, n);
+    std::vector<float> t;
+    for (int r = 0; r < 5; ++r) {
+        (void)hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_copy_b<B, NT>), dim3(grid), dim3(256), 0, 0, in, out, n);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); t.push_back(ms / 20);
+    }
+    std::sort(t.begin(), t.end());
+    printf("copy %-26s grid %5d  %7.1f us  %5.2f TB/s\n", name, grid, t[2] * 1e3, 2.0 * n * 8 / (t[2] * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const int64_t n = 4096ll * 4096 * 3;
+    if (argc > 1 && argv[1][0] == 'c') {            // readbench copysweep
+        double *a, *b;
+        (void)hipMalloc(&a, n * 8); (void)hipMalloc(&b, n * 8);
+        (void)hipMemset(a, 0, n * 8);
+        for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL((k_copy_b<1, true>), dim3(2048), dim3(256), 0, 0, a, b, n);
+        (void)hipDeviceSynchronize();
+        for (int grid : {768, 1024, 2048, 4096}) {
+            run_copy<1, true>(a, b, n, grid, "1 KB/wave nt");
+            run_copy<2, true>(a, b, n, grid, "2 KB/wave nt");
+            run_copy<4, true>(a, b, n, grid, "4 KB/wave nt");
+            run_copy<8, true>(a, b, n, grid, "8 KB/wave nt");
+            run_copy<16, true>(a, b, n, grid, "16 KB/wave nt");
+            run_copy<4, false>(a, b, n, grid, "4 KB/wave plain");
+        }
+        return 0;
+    }
     if (argc > 2) {            // readbench hold <read|fill> : keep one shape running for ~8 s (power / clock polling from outside)
         P q{};
         q.n = n;
