@@ -71,20 +71,34 @@ __global__ __launch_bounds__(256) void k_stride_probe(const uint32_t* __restrict
     }
     if (acc == 0x12345678u) sink[0] = acc;                                             // keeps the loads alive
 }
-// dst[i] = src[i] with 16-byte nontemporal accesses: the copy rate of the box (a 50 % read / 50 % write stream) is what the merge's
-// 47 % / 53 % traffic mix can be held against (bench.py: roofline.copy_GBps)
-__global__ __launch_bounds__(256) void k_copy_probe(const double* __restrict__ src, double* __restrict__ dst, int64_t n16) {
+// dst[i] = src[i], the copy shape that measured fastest on these boxes (tools/readbench.hip copysweep, profiles/r02h_copy_sweep.log): a wave
+// reads 4 KB (four 16-byte nontemporal loads per lane, 1 KB per instruction), then writes those 4 KB; 6.0-6.7 TB/s where one 16-byte
+// load + store per lane and step gets 5.3-5.9. The merge's traffic (47 % reads in seven byte streams, 53 % writes in one float64
+// stream) is held against this rate by bench.py (roofline.copy_GBps).
+constexpr int kCopyB = 4;
+__global__ __launch_bounds__(256) void k_copy_probe(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-    for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n16; q += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src) + q), reinterpret_cast<f64x2*>(dst) + q);
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t chunk = 128ll * kCopyB;                              // doubles per wave iteration
+    const int64_t wave0 = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * chunk;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 4 * chunk;
+    int64_t b = wave0;
+    for (; b + chunk <= n; b += stride) {
+        f64x2 v[kCopyB];
+#pragma unroll
+        for (int k = 0; k < kCopyB; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < kCopyB; ++k) __builtin_nontemporal_store(v[k], reinterpret_cast<f64x2*>(dst + b + 128 * k) + lane);
+    }
+    for (int64_t e = b + lane; e < n && e < b + chunk; e += 64) dst[e] = src[e];     // the last, partial chunk of the one wave that owns it
 }
 }  // namespace hm
 
 extern "C" int hm_debug_copy_probe(const void* src, void* dst, unsigned long long bytes, void* stream) {
     if (!src || !dst || bytes < 16 || (bytes & 15) || !hm::aligned(src, 16) || !hm::aligned(dst, 16)) return HM_EINVAL;
-    hipLaunchKernelGGL(hm::k_copy_probe, dim3(hm::stream_grid(static_cast<int64_t>(bytes / 16), 256, 8)), dim3(256), 0, hm::as_stream(stream),
-                       static_cast<const double*>(src), static_cast<double*>(dst), static_cast<int64_t>(bytes / 16));
+    const int64_t n = static_cast<int64_t>(bytes / 8);
+    hipLaunchKernelGGL(hm::k_copy_probe, dim3(hm::stream_grid((n + 512 * hm::kCopyB - 1) / (512 * hm::kCopyB), 1, 16)), dim3(256), 0, hm::as_stream(stream),
+                       static_cast<const double*>(src), static_cast<double*>(dst), n);
     return hm::launch_status();
 }
 

@@ -682,3 +682,16 @@ def test_per_frame_kernels_many_iterations():
     ow, odw = orc.gaussian_weight(x)
     np.testing.assert_allclose(w.cpu().numpy(), ow, rtol=1e-13, atol=1e-300)
     np.testing.assert_allclose(dw.cpu().numpy(), odw, rtol=1e-13, atol=1e-300)
+
+
+def test_debug_copy_probe_copies():
+    """hm_debug_copy_probe (the copy rate bench.py prints beside the roofline) really copies: whole 4 KB wave chunks, a partial last chunk,
+    a buffer smaller than one chunk."""
+    from camera_linearity_amd import _native as nat
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (2, 510, 512 * 4 * 7, 512 * 4 * 4096 + 1022, 3_000_002):
+        src = torch.rand(n, dtype=torch.float64, device="cuda")
+        dst = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+        nat.check(nat.lib.hm_debug_copy_probe(src.data_ptr(), dst.data_ptr(), n * 8, st), "copy probe")
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:n], src) and float(dst[n]) == 0.0 and float(dst[n + 1]) == 0.0
