@@ -101,6 +101,54 @@ __global__ __launch_bounds__(256) void k_binary_dense(const double* __restrict__
     }
 }
 
+// The same, in the access shape that measured fastest for plain copies on these boxes (tools/readbench.hip copysweep: 6.0-6.7 TB/s against
+// 5.3-5.9 for one 16-byte access per lane and step): a wave owns chunks of 512 consecutive elements and issues the four 16-byte loads per
+// lane of EVERY input stream back to back (4 KB per stream and wave), computes its 8 elements per lane, then issues the stores of every
+// output stream back to back. Whole chunks only; the host sends the remainder through k_binary_dense.
+constexpr int kBurst = 4;                                   // 16-byte accesses per lane, stream and chunk
+constexpr int64_t kBurstChunk = 128 * kBurst;               // elements per wave chunk
+template <int OP, bool S1, bool S2>
+__global__ __launch_bounds__(256) void k_binary_burst(const double* __restrict__ x1, const double* __restrict__ s1,
+                                                      const double* __restrict__ x2, const double* __restrict__ s2,
+                                                      double* __restrict__ out, double* __restrict__ out_std, int64_t n_chunks) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    constexpr bool STD = S1 || S2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t cstride = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t c = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); c < n_chunks; c += cstride) {
+        const int64_t b = c * kBurstChunk;
+        f64x2 a[kBurst], d[kBurst], sa[kBurst], sd[kBurst];
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) a[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x1 + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) d[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x2 + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) {
+            sa[k] = f64x2{0.0, 0.0};
+            if constexpr (S1) sa[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s1 + b + 128 * k) + lane);
+        }
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) {
+            sd[k] = f64x2{0.0, 0.0};
+            if constexpr (S2) sd[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s2 + b + 128 * k) + lane);
+        }
+        f64x2 r[kBurst], rs[kBurst];
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) {
+            double r0, r1, e0 = 0.0, e1 = 0.0;
+            binary_eval<OP>(a[k].x, sa[k].x, d[k].x, sd[k].x, STD, r0, e0);
+            binary_eval<OP>(a[k].y, sa[k].y, d[k].y, sd[k].y, STD, r1, e1);
+            r[k].x = r0; r[k].y = r1; rs[k].x = e0; rs[k].y = e1;
+        }
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) __builtin_nontemporal_store(r[k], reinterpret_cast<f64x2*>(out + b + 128 * k) + lane);
+        if constexpr (STD) {
+#pragma unroll
+            for (int k = 0; k < kBurst; ++k) __builtin_nontemporal_store(rs[k], reinterpret_cast<f64x2*>(out_std + b + 128 * k) + lane);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_unary(int op, const double* __restrict__ x, const double* __restrict__ s,
                                                double* __restrict__ out, double* __restrict__ out_std, int64_t n) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -260,6 +308,29 @@ extern "C" int hm_binary_op(int op, const double* x1, const double* s1, const do
     const bool al16 = aligned(x1, 16) && aligned(x2, 16) && aligned(out_val, 16) && (!s1 || aligned(s1, 16)) && (!s2 || aligned(s2, 16)) &&
                       (!out_std || aligned(out_std, 16));
     if (dense && al16 && op != HM_OP_POW) {
+#ifndef HM_NO_BURST
+        const int64_t n_chunks = n / kBurstChunk;
+        if (n_chunks > 0) {
+            const unsigned bgrid = stream_grid((n_chunks + 3) / 4, 1, 16);
+#define HM_BINB(O, A, B) hipLaunchKernelGGL((k_binary_burst<O, A, B>), dim3(bgrid), dim3(256), 0, st, x1, s1, x2, s2, out_val, out_std, n_chunks)
+#define HM_BINBS(O) do { if (s1 && s2) HM_BINB(O, true, true); else if (s1) HM_BINB(O, true, false); else if (s2) HM_BINB(O, false, true); \
+                         else HM_BINB(O, false, false); } while (0)
+            switch (op) {
+                case HM_OP_ADD: HM_BINBS(HM_OP_ADD); break;
+                case HM_OP_SUB: HM_BINBS(HM_OP_SUB); break;
+                case HM_OP_MUL: HM_BINBS(HM_OP_MUL); break;
+                default:        HM_BINBS(HM_OP_DIV); break;
+            }
+#undef HM_BINBS
+#undef HM_BINB
+            const int64_t done = n_chunks * kBurstChunk;                 // the remainder (< 512 elements) through the per-lane kernel below
+            if (done == n) return launch_status();
+            x1 += done; x2 += done; out_val += done; n -= done;
+            if (s1) s1 += done;
+            if (s2) s2 += done;
+            if (out_std) out_std += done;
+        }
+#endif
         const unsigned dgrid = stream_grid((n + 1) / 2, 256, 8);
 #define HM_BIND(O, A, B) hipLaunchKernelGGL((k_binary_dense<O, A, B>), dim3(dgrid), dim3(256), 0, st, x1, s1, x2, s2, out_val, out_std, n)
 #define HM_BINS(O) do { if (s1 && s2) HM_BIND(O, true, true); else if (s1) HM_BIND(O, true, false); else if (s2) HM_BIND(O, false, true); \
