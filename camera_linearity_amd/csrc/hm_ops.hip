@@ -238,6 +238,40 @@ __global__ __launch_bounds__(256) void k_pow_scalar(const double* __restrict__ x
     }
 }
 
+// pow with a scalar exponent in the burst access shape (k_binary_burst): whole 512-element chunks, 16-byte aligned buffers
+template <int KIND, bool STD>
+__global__ __launch_bounds__(256) void k_pow_scalar_burst(const double* __restrict__ x, const double* __restrict__ s, double* __restrict__ out,
+                                                          double* __restrict__ out_s, int64_t n_chunks, double p, int ip) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t cstride = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t c = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); c < n_chunks; c += cstride) {
+        const int64_t b = c * kBurstChunk;
+        f64x2 xv[kBurst], sv[kBurst];
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) xv[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) {
+            sv[k] = f64x2{0.0, 0.0};
+            if constexpr (STD) sv[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s + b + 128 * k) + lane);
+        }
+        f64x2 r[kBurst], e[kBurst];
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) {
+            double r0, r1, e0 = 0.0, e1 = 0.0;
+            pow_scalar_eval<KIND>(xv[k].x, sv[k].x, p, ip, STD, r0, e0);
+            pow_scalar_eval<KIND>(xv[k].y, sv[k].y, p, ip, STD, r1, e1);
+            r[k] = f64x2{r0, r1}; e[k] = f64x2{e0, e1};
+        }
+#pragma unroll
+        for (int k = 0; k < kBurst; ++k) __builtin_nontemporal_store(r[k], reinterpret_cast<f64x2*>(out + b + 128 * k) + lane);
+        if constexpr (STD) {
+#pragma unroll
+            for (int k = 0; k < kBurst; ++k) __builtin_nontemporal_store(e[k], reinterpret_cast<f64x2*>(out_s + b + 128 * k) + lane);
+        }
+    }
+}
+
 // take along one axis: out[o, k, i] = in[o, idx[k], i] for the (outer, axis_len, inner) view of a dense array
 // (modules/measurand.py:352-373, lib.take(val, dims, axis)). A pure gather copy: val and std in one launch.
 struct TakeK {
@@ -373,10 +407,27 @@ extern "C" int hm_pow_scalar(const double* x, const double* s, double exponent, 
     if (n == 0) return HM_OK;
     if (!x || !out_val || ((out_std != nullptr) != (s != nullptr))) return HM_EINVAL;
     if (!aligned(x, 8) || !aligned(out_val, 8)) return HM_EALIGN;
-    const unsigned grid = stream_grid((n + 1) / 2, 256, 8);
     hipStream_t st = as_stream(stream);
     const double p = exponent;
     const int ip = (p == static_cast<double>(static_cast<int>(p)) && p >= -8.0 && p <= 8.0) ? static_cast<int>(p) : 0;
+    // whole 512-element chunks of 16-byte aligned buffers in the burst access shape (the cheap exponents: a general pow() is compute-bound)
+    const bool al16 = aligned(x, 16) && aligned(out_val, 16) && (!s || (aligned(s, 16) && aligned(out_std, 16)));
+    const int64_t n_chunks = n / kBurstChunk;
+    if (al16 && n_chunks > 0 && (p == 2.0 || p == 0.5 || p == 1.0 || ip != 0)) {
+        const unsigned bgrid = stream_grid((n_chunks + 3) / 4, 1, 16);
+#define HM_POWB(K) do { if (s) hipLaunchKernelGGL((k_pow_scalar_burst<K, true>), dim3(bgrid), dim3(256), 0, st, x, s, out_val, out_std, n_chunks, p, ip); \
+                        else hipLaunchKernelGGL((k_pow_scalar_burst<K, false>), dim3(bgrid), dim3(256), 0, st, x, s, out_val, out_std, n_chunks, p, ip); } while (0)
+        if (p == 2.0) HM_POWB(POW_SQUARE);
+        else if (p == 0.5) HM_POWB(POW_SQRT);
+        else if (p == 1.0) HM_POWB(POW_ONE);
+        else HM_POWB(POW_INT);
+#undef HM_POWB
+        const int64_t done = n_chunks * kBurstChunk;
+        if (done == n) return launch_status();
+        x += done; out_val += done; n -= done;
+        if (s) { s += done; out_std += done; }
+    }
+    const unsigned grid = stream_grid((n + 1) / 2, 256, 8);
 #define HM_POW(K) hipLaunchKernelGGL(k_pow_scalar<K>, dim3(grid), dim3(256), 0, st, x, s, out_val, out_std, n, p, ip)
     if (p == 2.0) HM_POW(POW_SQUARE);
     else if (p == 0.5) HM_POW(POW_SQRT);

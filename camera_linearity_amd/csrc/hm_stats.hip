@@ -118,6 +118,69 @@ __global__ __launch_bounds__(256) void k_difference_dense(const double* __restri
     }
 }
 
+// the burst access shape (hm_ops.hip: k_binary_burst; tools/readbench.hip copysweep): a wave owns chunks of 512 elements, issues the four
+// 16-byte loads per lane of every input stream back to back, then the stores of every output stream. Whole chunks only.
+constexpr int kDiffBurst = 4;
+constexpr int64_t kDiffChunk = 128 * kDiffBurst;
+template <bool SX, bool SY>
+__global__ __launch_bounds__(256) void k_difference_burst(const double* __restrict__ x, const double* __restrict__ sx,
+                                                          const double* __restrict__ y, const double* __restrict__ sy, double mult,
+                                                          double* __restrict__ ad, double* __restrict__ ads,
+                                                          double* __restrict__ rd, double* __restrict__ rds, int64_t n_chunks) {
+    constexpr bool STD = SX || SY;
+    constexpr int B = kDiffBurst;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t cstride = static_cast<int64_t>(gridDim.x) * 4;
+    auto one = [&](double xv, double yv, double xs, double ys, double& a, double& r, double& as, double& rs) {
+        const double scale = mult * yv;                     // :634
+        a = xv - scale;                                     // :635
+        r = a / scale;                                      // :636
+        if constexpr (STD) {
+            const double m1 = mult * ys;
+            as = sqrt(xs * xs + m1 * m1);                   // :652
+            const double u1 = xs / (mult * yv);
+            const double u2 = (ys * xv) / (mult * (yv * yv));
+            rs = sqrt(u1 * u1 + u2 * u2);                   // :653
+        }
+    };
+    for (int64_t c = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); c < n_chunks; c += cstride) {
+        const int64_t b = c * kDiffChunk;
+        f64x2 xv[B], yv[B], xs[B], ys[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) xv[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < B; ++k) yv[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(y + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            xs[k] = f64x2{0.0, 0.0};
+            if constexpr (SX) xs[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sx + b + 128 * k) + lane);
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            ys[k] = f64x2{0.0, 0.0};
+            if constexpr (SY) ys[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(sy + b + 128 * k) + lane);
+        }
+        f64x2 a[B], r[B], as[B], rs[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            double a0, a1, r0, r1, as0 = 0.0, as1 = 0.0, rs0 = 0.0, rs1 = 0.0;
+            one(xv[k].x, yv[k].x, xs[k].x, ys[k].x, a0, r0, as0, rs0);
+            one(xv[k].y, yv[k].y, xs[k].y, ys[k].y, a1, r1, as1, rs1);
+            a[k] = f64x2{a0, a1}; r[k] = f64x2{r0, r1}; as[k] = f64x2{as0, as1}; rs[k] = f64x2{rs0, rs1};
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) __builtin_nontemporal_store(a[k], reinterpret_cast<f64x2*>(ad + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < B; ++k) __builtin_nontemporal_store(r[k], reinterpret_cast<f64x2*>(rd + b + 128 * k) + lane);
+        if constexpr (STD) {
+#pragma unroll
+            for (int k = 0; k < B; ++k) __builtin_nontemporal_store(as[k], reinterpret_cast<f64x2*>(ads + b + 128 * k) + lane);
+#pragma unroll
+            for (int k = 0; k < B; ++k) __builtin_nontemporal_store(rs[k], reinterpret_cast<f64x2*>(rds + b + 128 * k) + lane);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_interpolate(const double* __restrict__ x0, const double* __restrict__ s0,
                                                      const double* __restrict__ x1, const double* __restrict__ s1,
                                                      double y0, double y1, double y, double* __restrict__ out,
@@ -947,6 +1010,20 @@ extern "C" int hm_compute_difference(const double* x, const double* sx, const do
     const bool al16 = aligned(x, 16) && aligned(y, 16) && aligned(out_abs, 16) && aligned(out_rel, 16) && (!sx || aligned(sx, 16)) &&
                       (!sy || aligned(sy, 16)) && (!with_std || (aligned(out_abs_std, 16) && aligned(out_rel_std, 16)));
     if (al16) {
+        const int64_t n_chunks = n / kDiffChunk;
+        if (n_chunks > 0) {
+            const unsigned bgrid = stream_grid((n_chunks + 3) / 4, 1, 16);
+#define HM_DIFFB(A, B) hipLaunchKernelGGL((k_difference_burst<A, B>), dim3(bgrid), dim3(256), 0, as_stream(stream), \
+                                          x, sx, y, sy, multiplier, out_abs, out_abs_std, out_rel, out_rel_std, n_chunks)
+            if (sx && sy) HM_DIFFB(true, true); else if (sx) HM_DIFFB(true, false); else if (sy) HM_DIFFB(false, true); else HM_DIFFB(false, false);
+#undef HM_DIFFB
+            const int64_t done = n_chunks * kDiffChunk;                  // the remainder (< 512 elements) through the per-lane kernel
+            if (done == n) return launch_status();
+            x += done; y += done; out_abs += done; out_rel += done; n -= done;
+            if (sx) sx += done;
+            if (sy) sy += done;
+            if (out_abs_std) { out_abs_std += done; out_rel_std += done; }
+        }
         const unsigned dgrid = stream_grid((n + 1) / 2, 256, 8);
 #define HM_DIFF(A, B) hipLaunchKernelGGL((k_difference_dense<A, B>), dim3(dgrid), dim3(256), 0, as_stream(stream), \
                                          x, sx, y, sy, multiplier, out_abs, out_abs_std, out_rel, out_rel_std, n)
