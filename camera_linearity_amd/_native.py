@@ -86,7 +86,7 @@ _SIGNATURES = {
     "hm_pair_statistics": (C.c_int, [C.c_void_p] * 4 + [C.c_double, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hm_pairs_statistics_workspace_bytes": (C.c_size_t, [C.c_int]),
     "hm_pairs_statistics": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                      C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                      C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hm_histogram_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hm_channel_minmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hm_channel_histogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double,

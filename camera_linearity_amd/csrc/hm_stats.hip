@@ -720,6 +720,7 @@ struct PairsK {
     double mult[HM_PAIRS_MAX];
     int64_t n;
     int32_t C, n_pairs, with_std;
+    double lo[HM_MAX_CHANNELS], hi[HM_MAX_CHANNELS];        // apply_thresholds limits per channel (THR instantiations of the LDS kernel)
 };
 
 __global__ __launch_bounds__(1024) void k_pairs_stats(const PairsK a, double* __restrict__ partial) {
@@ -753,11 +754,16 @@ __global__ __launch_bounds__(1024) void k_pairs_stats(const PairsK a, double* __
 // The same statistics with the frames staged through LDS (the launch's usual shape: N >= 3 frames, all their pairs). In k_pairs_stats
 // every wave loads its own operands: 4 global loads per wave and chunk, 60 per workgroup for 14 distinct streams, and only the waves'
 // rough lock-step makes the other 46 hit in L1 / L2. Here the workgroup's threads copy each stream's two 512-byte chunks of an
-// iteration ONCE into LDS (16-byte items; item t of an iteration is stream t / 64, chunk (t % 64) / 32, piece t % 32 - NI = 1 or 2
-// items per thread) one iteration ahead of its use into one of three LDS stages, the loads in flight during the arithmetic before;
+// iteration ONCE into LDS (16-byte items; item t of an iteration is frame t / 64, chunk (t % 64) / 32, piece t % 32 of the value image and,
+// with stds, the same piece of the std image - NI = 1 or 2 items per thread) one iteration ahead of its use into one of three LDS stages, the loads in flight during the arithmetic before;
 // after one barrier per iteration every wave reads its pair's operands with conflict-free ds_read_b64. HBM sees the read-once
 // traffic, 1 KB per stream in flight per CU for a whole iteration, instead of 60 wave loads that mostly hit in cache.
-template <bool STD, int NI>
+// THR: AbstractMeasurand.apply_thresholds (modules/measurand.py:375-428) fused into the loader, which is the one place where every element of
+// every frame passes exactly once per launch: a value outside [lo, hi] of its channel becomes NaN together with its std, in the LDS copy AND in
+// the frame itself (a 16-byte store where something changed) - ExposureSeries.process_linearity (modules/exposure_series.py:437-441) leaves
+// its image sets thresholded. One thread stages a value item AND its std item, so the decision needs no second reader. Idempotent, so
+// the dropped re-read past the last whole iteration and a second launch over the same frames change nothing.
+template <bool STD, int NI, bool THR>
 __global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_frames, double* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char stage_mem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -770,32 +776,65 @@ __global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_
     const int ct = static_cast<int>((sb0 + lane) % a.C);
     const int n_streams = n_frames * (STD ? 2 : 1);
     const uint32_t stage_bytes = static_cast<uint32_t>(n_streams) * 1024u;
-    const int n_items = n_streams * 64;
-    // this thread's items: source pointer at iteration 0 and LDS byte offset inside a stage
+    const int n_items = n_frames * 64;                       // an item = 16 bytes (two elements) of one frame's value chunk - and of its std chunk
+    const uint32_t std_off = static_cast<uint32_t>(n_frames) * 1024u;
+    // this thread's items: source pointers at iteration 0; the LDS byte offset inside a stage is item * 16 (+ std_off for the std)
     const double* src[NI];
+    const double* ssrc[NI];
     bool have[NI];
+    double tlo[NI][2], thi[NI][2];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int item = static_cast<int>(threadIdx.x) + k * static_cast<int>(blockDim.x);
         have[k] = item < n_items;
         const int it_ = have[k] ? item : 0;
-        const int sidx = it_ >> 6, u = (it_ >> 5) & 1, piece = it_ & 31;
-        const double* base = sidx < n_frames ? a.val[sidx] : a.sd[sidx - n_frames];
-        src[k] = base + sb0 + u * stride + 2 * piece;
+        const int frame = it_ >> 6, u = (it_ >> 5) & 1, piece = it_ & 31;
+        const int64_t e0 = sb0 + u * stride + 2 * piece;
+        src[k] = a.val[frame] + e0;
+        ssrc[k] = STD ? a.sd[frame] + e0 : nullptr;
+        if constexpr (THR) {                                  // channels of the item's two elements: constant along the loop (step % C == 0)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = static_cast<int>((e0 + j) % a.C);
+                tlo[k][j] = c == 0 ? a.lo[0] : c == 1 ? a.lo[1] : c == 2 ? a.lo[2] : a.lo[3];
+                thi[k][j] = c == 0 ? a.hi[0] : c == 1 ? a.hi[1] : c == 2 ? a.hi[2] : a.hi[3];
+            }
+        }
     }
     auto whole = [&](int64_t b) { return b + (kPairUN - 1) * stride + 64 <= a.n; };
-    auto fetch = [&](int64_t delta, f64x2 (&r)[NI]) {                                           // delta = element offset of the iteration from sb0
+    struct Fetched { f64x2 v[NI]; f64x2 s[STD ? NI : 1]; int64_t delta; };
+    auto fetch = [&](int64_t delta, Fetched& f) {                                               // delta = element offset of the iteration from sb0
+        f.delta = delta;
 #pragma unroll
-        for (int k = 0; k < NI; ++k) r[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src[k] + delta));   // read once
+        for (int k = 0; k < NI; ++k) {
+            f.v[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(src[k] + delta));   // read once
+            if constexpr (STD) f.s[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(ssrc[k] + delta));
+        }
     };
-    auto stash = [&](int stage, const f64x2 (&r)[NI]) {
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    auto stash = [&](int stage, const Fetched& f) {
 #pragma unroll
-        for (int k = 0; k < NI; ++k)
-            if (have[k]) *reinterpret_cast<f64x2*>(stage_mem + stage * stage_bytes + (threadIdx.x + k * blockDim.x) * 16u) = r[k];
+        for (int k = 0; k < NI; ++k) {
+            f64x2 v = f.v[k], sd = STD ? f.s[k] : f64x2{0.0, 0.0};
+            if constexpr (THR) {                              // the value decides for itself and for its std (measurand.py:421-426; a NaN compares false)
+                const bool m0 = v.x < tlo[k][0] || v.x > thi[k][0], m1 = v.y < tlo[k][1] || v.y > thi[k][1];
+                v.x = m0 ? qnan : v.x; v.y = m1 ? qnan : v.y;
+                if constexpr (STD) { sd.x = m0 ? qnan : sd.x; sd.y = m1 ? qnan : sd.y; }
+                if (have[k] && (m0 || m1)) {                  // the frame itself, where it changed
+                    *reinterpret_cast<f64x2*>(const_cast<double*>(src[k]) + f.delta) = v;
+                    if constexpr (STD) *reinterpret_cast<f64x2*>(const_cast<double*>(ssrc[k]) + f.delta) = sd;
+                }
+            }
+            if (have[k]) {
+                char* dst = stage_mem + stage * stage_bytes + (threadIdx.x + k * blockDim.x) * 16u;
+                *reinterpret_cast<f64x2*>(dst) = v;
+                if constexpr (STD) *reinterpret_cast<f64x2*>(dst + std_off) = sd;
+            }
+        }
     };
     MomAcc st[2] = {acc_zero(), acc_zero()};
     const uint32_t ox = static_cast<uint32_t>(pi) * 1024u + lane * 8u, oy = static_cast<uint32_t>(pj) * 1024u + lane * 8u;
-    const uint32_t osx = ox + static_cast<uint32_t>(n_frames) * 1024u, osy = oy + static_cast<uint32_t>(n_frames) * 1024u;
+    const uint32_t osx = ox + std_off, osy = oy + std_off;
     auto compute = [&](int stage, int it) {
         const char* sm = stage_mem + stage * stage_bytes;
         double xv[kPairUN], yv[kPairUN], xs[kPairUN], ys[kPairUN];
@@ -815,7 +854,7 @@ __global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_
     // iteration the prefetch re-reads the current one (dropped) - no branch around a load, see pair_loop.
     int64_t sb = sb0;
     int it = 0, stage = 0;
-    f64x2 r[NI];
+    Fetched r;
     auto clamp = [&](int64_t b) { return (whole(b) ? b : sb) - sb0; };
     if (whole(sb)) { fetch(0, r); stash(0, r); fetch(clamp(sb + step), r); }
     while (whole(sb)) {
@@ -1087,11 +1126,18 @@ extern "C" size_t hm_pairs_statistics_workspace_bytes(int n_pairs) {
 
 extern "C" int hm_pairs_statistics(const double* const* vals, const double* const* stds, int n_frames, const int32_t* pair_i,
                                    const int32_t* pair_j, const double* multipliers, int n_pairs, int64_t n, int C,
+                                   const double* lower, const double* upper,
                                    double* out /*n_pairs * 6C*/, void* workspace, void* stream) {
     if (!vals || !pair_i || !pair_j || !multipliers || !out || !workspace || n < 1 || C < 1 || C > HM_MAX_CHANNELS) return HM_EINVAL;
-    if (n_frames < 1 || n_frames > HM_MAX_FRAMES || n_pairs < 1) return HM_EINVAL;
+    if (n_frames < 1 || n_frames > HM_MAX_FRAMES || n_pairs < 1 || ((lower != nullptr) != (upper != nullptr))) return HM_EINVAL;
+    const bool thr = lower != nullptr;
     PairsK k{};
     k.n = n; k.C = C; k.with_std = stds ? 1 : 0;
+    ChanLimits lim{};
+    for (int c = 0; c < HM_MAX_CHANNELS; ++c) {
+        k.lo[c] = lim.lo[c] = (thr && c < C) ? lower[c] : -__builtin_huge_val();
+        k.hi[c] = lim.hi[c] = (thr && c < C) ? upper[c] : __builtin_huge_val();
+    }
     for (int i = 0; i < n_frames; ++i) {
         if (!vals[i] || !aligned(vals[i], 8)) return HM_EINVAL;
         k.val[i] = vals[i];
@@ -1104,24 +1150,48 @@ extern "C" int hm_pairs_statistics(const double* const* vals, const double* cons
     int64_t g = (n + 63) / 64;
     g = ((g + 11) / 12) * 12;
     const int grid = static_cast<int>(g < kStatBlocks ? g : kStatBlocks);
+    const int n_streams = n_frames * (stds ? 2 : 1);
+    bool al16 = true;
+    for (int i = 0; i < n_frames; ++i) al16 = al16 && aligned(vals[i], 16) && (!stds || aligned(stds[i], 16));
+    // the thresholds (in place, as apply_thresholds does) ride on the first launch's loader when that launch stages the frames through LDS:
+    // every element below `fused_end` lies in an iteration that is whole for every workgroup. The rest - and everything when the first
+    // launch cannot use the LDS kernel - goes through k_thresholds first.
+    auto lds_ok = [&](int np) { return al16 && n_frames * 64 <= 2 * 64 * np && n_streams <= 21; };
+    const int np_first = n_pairs < HM_PAIRS_MAX ? n_pairs : HM_PAIRS_MAX;
+    bool fuse_thr = false;
+    if (thr) {
+        const int64_t stride = static_cast<int64_t>(grid) * 64;
+        int64_t whole_all = 0;                                               // iterations that are whole for the LAST workgroup (hence for all)
+        while ((static_cast<int64_t>(grid) - 1) * 64 + (2 * whole_all + 1) * stride + 64 <= n) ++whole_all;
+        const int64_t fused_end = lds_ok(np_first) ? 2 * stride * whole_all : 0;         // a multiple of C (stride is)
+        fuse_thr = fused_end > 0;
+        if (fused_end < n) {
+            const int64_t m = n - fused_end;
+            for (int i = 0; i < n_frames; ++i) {
+                double* v = const_cast<double*>(vals[i]) + fused_end;
+                double* sdp = stds ? const_cast<double*>(stds[i]) + fused_end : nullptr;
+                hipLaunchKernelGGL(k_thresholds, dim3(stream_grid((m + 1) / 2, 256, 8)), dim3(256), 0, st, v, sdp, lim, m, C);
+            }
+        }
+    }
     for (int p0 = 0; p0 < n_pairs; p0 += HM_PAIRS_MAX) {                 // HM_PAIRS_MAX pairs (waves of a workgroup) per launch
         const int np = n_pairs - p0 < HM_PAIRS_MAX ? n_pairs - p0 : HM_PAIRS_MAX;
         k.n_pairs = np;
         for (int p = 0; p < np; ++p) { k.pi[p] = pair_i[p0 + p]; k.pj[p] = pair_j[p0 + p]; k.mult[p] = multipliers[p0 + p]; }
         // frames through LDS when a workgroup's threads can copy an iteration's 64 * n_streams 16-byte items with at most two each
-        const int n_streams = n_frames * (stds ? 2 : 1);
-        const int items = n_streams * 64, threads = 64 * np;
-        bool al16 = true;
-        for (int i = 0; i < n_frames; ++i) al16 = al16 && aligned(vals[i], 16) && (!stds || aligned(stds[i], 16));
-        if (al16 && items <= 2 * threads && n_streams <= 21) {                                   // 3 stages x n_streams KB <= 64 KB of LDS
+        const int items = n_frames * 64, threads = 64 * np;          // one item = 16 bytes of a frame's value chunk (+ the same of its std)
+        if (lds_ok(np)) {                                                                   // 3 stages x n_streams KB <= 64 KB of LDS
             const size_t lds = 3u * static_cast<size_t>(n_streams) * 1024u;
+            const bool t_ = fuse_thr && p0 == 0;
+#define HM_PLDS(S, N, T) hipLaunchKernelGGL((k_pairs_stats_lds<S, N, T>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial)
             if (stds) {
-                if (items <= threads) hipLaunchKernelGGL((k_pairs_stats_lds<true, 1>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
-                else hipLaunchKernelGGL((k_pairs_stats_lds<true, 2>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
+                if (items <= threads) { if (t_) HM_PLDS(true, 1, true); else HM_PLDS(true, 1, false); }
+                else { if (t_) HM_PLDS(true, 2, true); else HM_PLDS(true, 2, false); }
             } else {
-                if (items <= threads) hipLaunchKernelGGL((k_pairs_stats_lds<false, 1>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
-                else hipLaunchKernelGGL((k_pairs_stats_lds<false, 2>), dim3(grid), dim3(threads), lds, st, k, n_frames, partial);
+                if (items <= threads) { if (t_) HM_PLDS(false, 1, true); else HM_PLDS(false, 1, false); }
+                else { if (t_) HM_PLDS(false, 2, true); else HM_PLDS(false, 2, false); }
             }
+#undef HM_PLDS
         } else
             hipLaunchKernelGGL(k_pairs_stats, dim3(grid), dim3(64 * np), 0, st, k, partial);
         hipLaunchKernelGGL(k_pairs_final, dim3(np, 2 * C), dim3(256), 0, st, partial, grid, np, C, k.with_std, out + static_cast<int64_t>(p0) * 6 * C);

@@ -609,22 +609,34 @@ def pair_statistics(x, sx, y, sy, multiplier: float):
     return mk(0), mk(3 * Cc)
 
 
-def pairs_statistics(vals: Sequence[torch.Tensor], stds: Optional[Sequence[torch.Tensor]], pairs: Sequence[tuple], to_host: bool = False):
+def pairs_statistics(vals: Sequence[torch.Tensor], stds: Optional[Sequence[torch.Tensor]], pairs: Sequence[tuple], to_host: bool = False,
+                     thresholds: Optional[tuple] = None):
     """Statistics of the absolute and relative difference of EVERY exposure pair of a stack in one fused launch
     (hm_pairs_statistics; modules/exposure_series.py:421-446). `pairs` = [(i, j, multiplier), ...] with i the short and j the
-    long exposure. Returns one (abs_stats, rel_stats) tuple of dicts per pair, as pair_statistics() does."""
+    long exposure. Returns one (abs_stats, rel_stats) tuple of dicts per pair, as pair_statistics() does.
+    thresholds = (lower, upper), C numbers each: apply_thresholds(lower, upper) is applied to every frame (and std) IN PLACE first,
+    fused into the launch's loads - the frames must then be the contiguous float64 tensors the caller keeps."""
     n = len(vals)
     for i, v in enumerate(vals):
         _require_cuda(v, f"vals[{i}]")
         if v.shape != vals[0].shape or v.dtype != _F64:
             raise ValueError("pairs_statistics needs float64 frames of one shape")
     dev = vals[0].device
+    if thresholds is not None and (any(not v.is_contiguous() for v in vals) or
+                                   (stds is not None and any(s is None or s.dtype != _F64 or not s.is_contiguous() for s in stds))):
+        raise ValueError("in-place thresholds need contiguous float64 frames (and stds)")
     vals = [v.contiguous() for v in vals]
     if stds is not None:
         if len(stds) != n or any(s is None for s in stds):
             raise ValueError("one std frame per value frame (or none at all)")
         stds = [s.to(_F64).contiguous() for s in stds]
     Cc = vals[0].shape[-1]
+    lo = hi = None
+    if thresholds is not None:
+        if len(thresholds[0]) != Cc or len(thresholds[1]) != Cc:
+            raise ValueError("The length of 'lower' and 'upper' must match the size of the independent axis.")
+        lo = (C.c_double * Cc)(*[float(x) for x in thresholds[0]])
+        hi = (C.c_double * Cc)(*[float(x) for x in thresholds[1]])
     P = len(pairs)
     vp = _ptr_array(vals)
     sp = None if stds is None else _ptr_array(stds)
@@ -635,7 +647,7 @@ def pairs_statistics(vals: Sequence[torch.Tensor], stds: Optional[Sequence[torch
     ws = torch.empty(max(1, nat.lib.hm_pairs_statistics_workspace_bytes(P) // 8), dtype=_F64, device=dev)
     with torch.cuda.device(dev):
         nat.check(nat.lib.hm_pairs_statistics(C.cast(vp, C.POINTER(C.c_void_p)), None if sp is None else C.cast(sp, C.POINTER(C.c_void_p)), n,
-                                              pi, pj, pm, P, vals[0].numel(), Cc, out.data_ptr(), ws.data_ptr(), _stream(dev)),
+                                              pi, pj, pm, P, vals[0].numel(), Cc, lo, hi, out.data_ptr(), ws.data_ptr(), _stream(dev)),
                   "hm_pairs_statistics")
     w = stds is not None
     if to_host:

@@ -13,6 +13,8 @@ loaded from `path` only when an ImageSet holds no pixels yet).
 """
 from __future__ import annotations
 
+import math
+
 from pathlib import Path
 from typing import Dict, List, Optional
 
@@ -291,6 +293,10 @@ class ExposureSeries(object):
                 image_set.load_value_image()
             if image_set.measurand.std is None and use_std:
                 image_set.load_std_image()
+        # the thresholds ride on the all-pairs launch where that applies (no separate pass over the frames); otherwise frame by frame
+        if self._all_pairs_fused(lower, upper):
+            return
+        for image_set in self.input_image_sets:
             image_set.measurand.apply_thresholds(lower, upper)
         if self._all_pairs_fused():
             return
@@ -302,7 +308,7 @@ class ExposureSeries(object):
                 pair.compute_difference()
                 pair.compute_stats(axis=(0, 1), release_memory_after=True)
 
-    def _all_pairs_fused(self) -> bool:
+    def _all_pairs_fused(self, lower=None, upper=None) -> bool:
         """Every pair of the series in ONE launch (hm_pairs_statistics): each frame is read from HBM once instead of once per
         pair it takes part in. Applies when the pairs are pairs of this series' own images, all images share one (H, W, C <= 4)
         shape on one device and either all or none of them carry a std; otherwise the per-pair path above runs."""
@@ -324,7 +330,23 @@ class ExposureSeries(object):
             return False
         stds = [s.measurand.std for s in sets] if all(have_std) else None
         pairs = [(index[id(p.short_exposure)], index[id(p.long_exposure)], p.exposure_ratio) for p in self.exposure_pairs]
-        for p, (ab, rel) in zip(self.exposure_pairs, engine.pairs_statistics(vals, stds, pairs, to_host=True)):
+        thresholds = None
+        if lower is not None or upper is not None:           # apply_thresholds (measurand.py:375-428) inside the launch, in place
+            n_ch = vals[0].shape[-1]
+            lower = [None] * n_ch if lower is None else lower
+            upper = [None] * n_ch if upper is None else upper
+            if len(lower) != n_ch or len(upper) != n_ch:
+                raise ValueError("The length of 'lower' and 'upper' must match the size of the independent axis.")
+            thresholds = ([-math.inf if l is None else l for l in lower], [math.inf if u is None else u for u in upper])
+            vals = [v.contiguous() for v in vals]
+            if stds is not None:
+                stds = [sd.to(torch.float64).contiguous() for sd in stds]
+            for s_, v in zip(sets, vals):                      # the image sets keep the tensors that are thresholded in place
+                s_.measurand.val = v
+            if stds is not None:
+                for s_, sd in zip(sets, stds):
+                    s_.measurand.std = sd
+        for p, (ab, rel) in zip(self.exposure_pairs, engine.pairs_statistics(vals, stds, pairs, to_host=True, thresholds=thresholds)):
             p.absolute_stats, p.relative_stats = ab, rel          # (host tensors: 6C numbers per pair, fetched with ONE copy)
             p.absolute_difference = p.relative_difference = None
         return True

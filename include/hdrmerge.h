@@ -257,12 +257,17 @@ int hm_pair_statistics(const double* x, const double* sx, const double* y, const
  * frame pair_i[p] (short) with frame pair_j[p] (long) scaled by multipliers[p] (their exposure ratio) and gets the six
  * statistics of hm_pair_statistics at out[p * 6C ...]. One launch per HM_PAIRS_MAX pairs: a workgroup owns a run of elements,
  * each of its waves one pair, so a frame is read from HBM once per launch instead of once per pair it takes part in.
- * vals / stds: [host] arrays of n_frames device pointers (stds NULL = unweighted); pair_i / pair_j / multipliers: [host]. */
+ * vals / stds: [host] arrays of n_frames device pointers (stds NULL = unweighted); pair_i / pair_j / multipliers: [host].
+ * lower / upper: [host] C limits each, or both NULL. When given, hm_apply_thresholds(lower, upper) is applied to EVERY frame (and its
+ * std) IN PLACE before it is compared - the apply_thresholds loop of process_linearity (modules/exposure_series.py:437-441), which leaves
+ * the series' image sets thresholded - fused into the first launch's loads where the frames are staged through LDS (no separate pass
+ * over the frames), by thresholding kernels otherwise; the result is the same either way. */
 #define HM_PAIRS_MAX 16
 size_t hm_pairs_statistics_workspace_bytes(int n_pairs);
 int hm_pairs_statistics(const double* const* vals, const double* const* stds /*nullable*/, int n_frames,
                         const int32_t* pair_i, const int32_t* pair_j, const double* multipliers, int n_pairs,
-                        int64_t n, int C, double* out /*n_pairs * 6C*/, void* workspace, void* stream);
+                        int64_t n, int C, const double* lower /*nullable*/, const double* upper /*nullable*/,
+                        double* out /*n_pairs * 6C*/, void* workspace, void* stream);
 /* hm_channel_histogram: compute_channel_histogram (modules/measurand.py:430-469) = np.histogram per channel on
  * [lo, hi] with `bins` equal-width bins (edges = np.linspace(lo, hi, bins + 1) on the device), non-finite values
  * skipped, optional weights 1/std with zero stds skipped. out is (C, bins) float64; channels not in

@@ -695,3 +695,57 @@ def test_debug_copy_probe_copies():
         nat.check(nat.lib.hm_debug_copy_probe(src.data_ptr(), dst.data_ptr(), n * 8, st), "copy probe")
         torch.cuda.synchronize()
         assert torch.equal(dst[:n], src) and float(dst[n]) == 0.0 and float(dst[n + 1]) == 0.0
+
+
+@pytest.mark.parametrize("use_std", [True, False])
+@pytest.mark.parametrize("h,w", [(37, 29), (640, 512)])
+def test_process_linearity_thresholds_in_place(use_std, h, w):
+    """process_linearity leaves the series' image sets thresholded (modules/exposure_series.py:437-441 calls apply_thresholds in place) and
+    compares the thresholded frames. Here the thresholds ride on the all-pairs launch: whole iterations are thresholded by the LDS loader,
+    the ragged rest by hm_apply_thresholds' kernel (small image: everything by the latter). Afterwards every image set must hold exactly
+    what the oracle's apply_thresholds gives (same NaNs, untouched values bit for bit), and the statistics must be those of the
+    thresholded frames; a second call changes nothing."""
+    from camera_linearity_amd import _native as nat
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    n = 5
+    frames, stds, _ = orc.synthetic_stack(21, n, h, w, with_std=True)
+    t = 1e-3 * 1.7 ** np.arange(n)
+    sets = [ImageSet(value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
+    series = ExposureSeries(input_image_sets=sets)
+    series.initialize_exposure_pairs()
+    icrf, _ = orc.synthetic_icrf((1.0, 1.0, 1.0))
+    before = nat.lib.calls["hm_pairs_statistics"]
+    thr_calls = nat.lib.calls["hm_apply_thresholds"]
+    series.process_linearity(icrf, linearity_limit=25, use_std=use_std)
+    assert nat.lib.calls["hm_pairs_statistics"] == before + 1
+    assert nat.lib.calls["hm_apply_thresholds"] == thr_calls                  # no separate thresholding pass from the host side
+    lo, hi = icrf[25, 0], icrf[255 - 25, 0]
+    th = [orc.apply_thresholds(orc.unit_from_u8(f), s if use_std else None, [lo] * 3, [hi] * 3) for f, s in zip(frames, stds)]
+    assert any(np.isnan(v).any() for v, _ in th) and any(np.isfinite(v).any() for v, _ in th)
+    for s_, (rv, rs) in zip(sets, th):
+        gv, gs = s_.measurand.to_numpy() if hasattr(s_.measurand, "to_numpy") else (s_.measurand.val.cpu().numpy(), None)
+        np.testing.assert_array_equal(np.asarray(gv), rv)
+        if use_std:
+            np.testing.assert_array_equal(np.asarray(gs), rs)
+    k = 0
+    for i in range(n):
+        for j in range(n):
+            if i >= j or t[i] / t[j] < 0.1:
+                continue
+            p = series.exposure_pairs[k]
+            k += 1
+            ad, ads, rd, rds = orc.compute_difference(th[i][0], th[i][1], th[j][0], th[j][1], t[i] / t[j])
+            for got, dv, ds in ((p.absolute_stats, ad, ads), (p.relative_stats, rd, rds)):
+                ref = orc.dimension_statistics(dv, ds, (0, 1))
+                for key in ("mean", "std", "error"):
+                    if ref[key] is None:
+                        assert got[key] is None
+                        continue
+                    np.testing.assert_allclose(got[key].cpu().numpy(), ref[key], rtol=1e-11)
+    assert k == len(series.exposure_pairs)
+    first = [(p.absolute_stats["mean"].clone(), p.relative_stats["std"].clone()) for p in series.exposure_pairs]
+    series.process_linearity(icrf, linearity_limit=25, use_std=use_std)            # idempotent
+    for p, (m_, s__) in zip(series.exposure_pairs, first):
+        assert np.array_equal(p.absolute_stats["mean"].cpu().numpy(), m_.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(p.relative_stats["std"].cpu().numpy(), s__.cpu().numpy(), equal_nan=True)

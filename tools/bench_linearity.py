@@ -52,9 +52,13 @@ for use_std in (False, True):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     t_all = timed(lambda: engine.pairs_statistics(vals, sds, pairs))
+    from camera_linearity_amd.exposure_series import map_linearity_limits
+    lo_, hi_ = map_linearity_limits(5, 5, icrf)
+    t_thr = timed(lambda: engine.pairs_statistics(vals, sds, pairs, thresholds=(lo_, hi_)))
+    t_sep = timed(lambda: [engine.apply_thresholds_(v_, None if sds is None else sds[i_], lo_, hi_) for i_, v_ in enumerate(vals)])
     t_each = timed(lambda: [engine.pair_statistics(vals[i], None if sds is None else sds[i], vals[j], None if sds is None else sds[j], m) for i, j, m in pairs])
     once = n * (2 if use_std else 1) * 8 * E                            # every frame (+ std) read once
     nan_frac = sum(float(torch.isnan(v_).double().mean()) for v_ in vals) / len(vals)
-    print(f"smooth={SMOOTH} NaN fraction {nan_frac:.2f} use_std={use_std}: {npairs} pairs; process_linearity end to end {dt * 1e3:.1f} ms; hm_pairs_statistics alone {t_all:.2f} ms "
+    print(f"smooth={SMOOTH} NaN fraction {nan_frac:.2f} use_std={use_std}: {npairs} pairs; process_linearity end to end {dt * 1e3:.1f} ms; hm_pairs_statistics alone {t_all:.2f} ms, with the thresholds fused {t_thr:.2f} ms ({len(vals)} x hm_apply_thresholds alone: {t_sep:.2f} ms) "
           f"({once / t_all / 1e9:.2f} TB/s of read-once traffic); {npairs} x hm_pair_statistics {t_each:.2f} ms", flush=True)
     del sets, series
