@@ -698,8 +698,8 @@ def test_debug_copy_probe_copies():
 
 
 @pytest.mark.parametrize("use_std", [True, False])
-@pytest.mark.parametrize("h,w", [(37, 29), (640, 512)])
-def test_process_linearity_thresholds_in_place(use_std, h, w):
+@pytest.mark.parametrize("h,w,n", [(37, 29, 5), (640, 512, 5), (320, 512, 7)])
+def test_process_linearity_thresholds_in_place(use_std, h, w, n):
     """process_linearity leaves the series' image sets thresholded (modules/exposure_series.py:437-441 calls apply_thresholds in place) and
     compares the thresholded frames. Here the thresholds ride on the all-pairs launch: whole iterations are thresholded by the LDS loader,
     the ragged rest by hm_apply_thresholds' kernel (small image: everything by the latter). Afterwards every image set must hold exactly
@@ -708,9 +708,8 @@ def test_process_linearity_thresholds_in_place(use_std, h, w):
     from camera_linearity_amd import _native as nat
     from camera_linearity_amd.exposure_series import ExposureSeries
     from camera_linearity_amd.image_set import ImageSet
-    n = 5
     frames, stds, _ = orc.synthetic_stack(21, n, h, w, with_std=True)
-    t = 1e-3 * 1.7 ** np.arange(n)
+    t = 1e-3 * (1.7 if n == 5 else 1.6) ** np.arange(n)                       # n = 7: 18 pairs, i.e. two launches (HM_PAIRS_MAX = 16)
     sets = [ImageSet(value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
     series = ExposureSeries(input_image_sets=sets)
     series.initialize_exposure_pairs()
