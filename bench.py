@@ -475,9 +475,14 @@ def main():
     # the box's copy rate (the library's nontemporal 16-byte copy kernel between two output buffers, after the timed region): the merge's
     # traffic is ~half reads, ~half writes, and a plain copy is what the memory system sustains for such a mix
     copy_gbps = None
-    if rank == 0 and len(plans) > 1 and "val" in plans[0].outputs and "val" in plans[1].outputs:
+    pair_ = None
+    if len(plans) > 1 and "val" in plans[0].outputs and "val" in plans[1].outputs:
+        pair_ = (plans[0].outputs["val"], plans[1].outputs["val"])
+    elif "val" in plans[0].outputs and "std" in plans[0].outputs:
+        pair_ = (plans[0].outputs["val"], plans[0].outputs["std"])
+    if rank == 0 and pair_ is not None:
         from camera_linearity_amd import _native as nat
-        src, dst = plans[0].outputs["val"], plans[1].outputs["val"]
+        src, dst = pair_
         nbytes = src.numel() * 8
         st_ = torch.cuda.current_stream(dev).cuda_stream
         for _ in range(20):
@@ -490,7 +495,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         copy_gbps = 2 * nbytes / (e0.elapsed_time(e1) * 1e-3 / 100) / 1e9
-        plans[0].launch(); plans[1].launch()                      # restore the outputs the CPU leg will check
+        for p_ in plans[:2]:                                       # restore the outputs the CPU leg will check
+            p_.launch()
         torch.cuda.synchronize()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
