@@ -194,6 +194,50 @@ __global__ __launch_bounds__(256) void k_interpolate(const double* __restrict__ 
     }
 }
 
+// interpolate in the burst access shape (k_difference_burst): whole 512-element chunks of 16-byte aligned, dense buffers
+template <bool S0, bool S1>
+__global__ __launch_bounds__(256) void k_interpolate_burst(const double* __restrict__ x0, const double* __restrict__ s0,
+                                                           const double* __restrict__ x1, const double* __restrict__ s1,
+                                                           double y0, double y1, double y, double* __restrict__ out,
+                                                           double* __restrict__ out_std, int64_t n_chunks) {
+    constexpr bool STD = S0 || S1;
+    constexpr int B = kDiffBurst;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t cstride = static_cast<int64_t>(gridDim.x) * 4;
+    const double a = y1 - y, b = y - y0, d = y1 - y0;
+    const double ca = (a / d) * (a / d), cb = (b / d) * (b / d);
+    for (int64_t c = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); c < n_chunks; c += cstride) {
+        const int64_t e = c * kDiffChunk;
+        f64x2 v0[B], v1[B], u0[B], u1[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) v0[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x0 + e + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < B; ++k) v1[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(x1 + e + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            u0[k] = f64x2{0.0, 0.0};
+            if constexpr (S0) u0[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s0 + e + 128 * k) + lane);
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            u1[k] = f64x2{0.0, 0.0};
+            if constexpr (S1) u1[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(s1 + e + 128 * k) + lane);
+        }
+        f64x2 o[B], os[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            o[k] = f64x2{(v0[k].x * a + v1[k].x * b) / d, (v0[k].y * a + v1[k].y * b) / d};             // :665
+            os[k] = f64x2{sqrt(u0[k].x * ca + u1[k].x * cb), sqrt(u0[k].y * ca + u1[k].y * cb)};       // :679 as written
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) __builtin_nontemporal_store(o[k], reinterpret_cast<f64x2*>(out + e + 128 * k) + lane);
+        if constexpr (STD) {
+#pragma unroll
+            for (int k = 0; k < B; ++k) __builtin_nontemporal_store(os[k], reinterpret_cast<f64x2*>(out_std + e + 128 * k) + lane);
+        }
+    }
+}
+
 // ---- statistics -------------------------------------------------------------------------------
 // compute_dimension_statistics (modules/measurand.py:318-350) in ONE pass over the data. The reference's two NumPy passes
 // (mean, then sum of squared deviations from it) would read every byte twice; here every thread keeps a running (W, mean, M2)
@@ -1080,6 +1124,22 @@ extern "C" int hm_interpolate(const double* x0, const double* s0, const double* 
     if (n < 0) return HM_EINVAL;
     if (n == 0) return HM_OK;
     if (!x0 || !x1 || !out || ((s0 || s1) != (out_std != nullptr))) return HM_EINVAL;
+    const bool al16 = aligned(x0, 16) && aligned(x1, 16) && aligned(out, 16) && (!s0 || aligned(s0, 16)) && (!s1 || aligned(s1, 16)) &&
+                      (!out_std || aligned(out_std, 16));
+    const int64_t n_chunks = n / kDiffChunk;
+    if (al16 && n_chunks > 0) {
+        const unsigned bgrid = stream_grid((n_chunks + 3) / 4, 1, 16);
+#define HM_INTB(A, B) hipLaunchKernelGGL((k_interpolate_burst<A, B>), dim3(bgrid), dim3(256), 0, as_stream(stream), \
+                                         x0, s0, x1, s1, y0, y1, y, out, out_std, n_chunks)
+        if (s0 && s1) HM_INTB(true, true); else if (s0) HM_INTB(true, false); else if (s1) HM_INTB(false, true); else HM_INTB(false, false);
+#undef HM_INTB
+        const int64_t done = n_chunks * kDiffChunk;                      // the remainder (< 512 elements) through the per-lane kernel
+        if (done == n) return launch_status();
+        x0 += done; x1 += done; out += done; n -= done;
+        if (s0) s0 += done;
+        if (s1) s1 += done;
+        if (out_std) out_std += done;
+    }
     hipLaunchKernelGGL(k_interpolate, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream),
                        x0, s0, x1, s1, y0, y1, y, out, out_std, n);
     return launch_status();

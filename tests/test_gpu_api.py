@@ -585,6 +585,14 @@ def test_dense_and_general_kernel_paths_agree(offset, n):
     oad, oads, ord_, ords = orc.compute_difference(x, sx, y, sy, mult)
     for got, ref in ((ad, oad), (ads, oads), (rd, ord_), (rds, ords)):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-14)
+    for a_, b_ in ((dev["sx"], dev["sy"]), (dev["sx"], None), (None, None)):
+        iv, is_ = engine.interpolate(dev["x"], a_, dev["y"], b_, 0.004, 0.016, 0.007)
+        ov, os2 = orc.interpolate(x, None if a_ is None else sx, y, None if b_ is None else sy, 0.004, 0.016, 0.007)
+        np.testing.assert_allclose(iv.cpu().numpy(), ov, rtol=1e-15)
+        if os2 is None:
+            assert is_ is None
+        else:
+            np.testing.assert_allclose(is_.cpu().numpy(), os2, rtol=1e-14)
     # statistics on (n // 3, 3) views: channel and pair kernels on the same unaligned / odd data
     m = (n // 3) * 3
     as3 = lambda t_: t_[:m].reshape(-1, 3)     # noqa: E731
