@@ -21,14 +21,44 @@ import argparse
 import json
 import os
 import pathlib
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# numpy and torch are imported by main() AFTER the self-launch decision (late_imports): the parent of an N > 1 run must not
+# have touched torch (let alone HIP) when it starts its ranks as a child process (tests/test_host_logic.py holds it to that).
+np = None
+torch = None
 
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+
+
+def late_imports():
+    global np, torch
+    import numpy
+    import torch as torch_
+    np, torch = numpy, torch_
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(gpus, argv, runner=None):
+    """`python bench.py --gpus N` (N > 1) from a plain shell: start the N ranks as a CHILD process - the same command the
+    driver would type (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same arguments>) - wait for it and return its exit code. Rank 0 of the child prints the JSON line on the
+    inherited stdout. Nothing in this process has imported torch or made a HIP call at this point, and nothing is exec'ed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(ROOT / "bench.py")] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return (runner or subprocess.run)(cmd, env=env).returncode
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -65,6 +95,21 @@ def cpu_baseline_threaded(frames, t, icrf, diff, stds, rows, threads):
     with ThreadPoolExecutor(max_workers=threads) as pool:
         list(pool.map(one, bands))
     return time.perf_counter() - t0
+
+
+def rank_report(dist, a, dev, elapsed, avg_us):
+    """max-over-ranks elapsed time + what every rank measured for itself (all-gathered): the N > 1 line shows how many ranks
+    took part and the spread of their average launch durations, so a straggler GPU is visible."""
+    if dist is None:
+        return elapsed, None
+    on = dev if a.dist_backend == "nccl" else "cpu"
+    mine = torch.tensor([elapsed, avg_us], dtype=torch.float64, device=on)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    el = [float(x[0]) for x in every]
+    us = [float(x[1]) for x in every]
+    return max(el), {"ranks_seen": len(every), "avg_launch_us_min": round(min(us), 2), "avg_launch_us_max": round(max(us), 2),
+                     "avg_launch_us_per_rank": [round(x, 2) for x in us], "elapsed_s_per_rank": [round(x, 5) for x in el]}
 
 
 DARK_THR = 0.05                 # pixel threshold of the dark maps (settings.DARK_THRESHOLD)
@@ -189,10 +234,7 @@ def row_tile_workload(a, dev, rank, world, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps / max(n_launch, 1)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, ranks = rank_report(dist, a, dev, elapsed, avg_us)
     # host-side assembly of the image (once, untimed for `value`)
     gloo = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
     barrier()
@@ -235,6 +277,7 @@ def row_tile_workload(a, dev, rank, world, dist):
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None, "kernel": plan0.kernels,
                              "algorithmic_bytes_per_launch": alg // n_launch, "avg_launch_us": round(avg_us, 2)},
+                "ranks": ranks,
                 "assembly_ms": round(assembly_ms, 1),
                 "assembly": f"{n_tiles} tiles -> pinned host buffers (async D2H on a side stream) -> one {H}x{W}x3 float64 image"
                             + (" (+ std)" if with_std else "") + " on rank 0",
@@ -244,9 +287,10 @@ def row_tile_workload(a, dev, rank, world, dist):
         dist.destroy_process_group()
 
 
-def producer_workload(a, dev):
-    """The SURVEY.md 8(f) rows as bench workloads (one GPU): same timing discipline as the merge (pre-warm, warm-up, K
-    launches between two events) and a cpu_baseline leg = the oracle on a bounded sample. Prints one JSON line."""
+def producer_workload(a, dev, rank=0, world=1, dist=None):
+    """The SURVEY.md 8(f) rows as bench workloads: same timing discipline as the merge (pre-warm, warm-up, K launches
+    between two events) and a cpu_baseline leg = the oracle on a bounded sample (N = 1 only). At N > 1 every rank runs its own
+    replica of the workload (no exchange step: "replicas only"). Rank 0 prints one JSON line."""
     from camera_linearity_amd import engine, _native as nat
     steps, warmup = min(a.steps, 50), min(a.warmup, 5)
     if a.workload == "welford":
@@ -282,17 +326,28 @@ def producer_workload(a, dev):
     for _ in range(warmup):
         launch()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
         launch()
     ev1.record()
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     avg_us = ev0.elapsed_time(ev1) * 1e3 / steps
+    elapsed, ranks = rank_report(dist, a, dev, elapsed, avg_us)
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     cpu = None
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:
         from oracle import hdr_oracle as orc
         if a.workload == "welford":
             sample = [f[:2048].cpu().numpy() for f in clip]
@@ -310,13 +365,13 @@ def producer_workload(a, dev):
             cpu = {"value": round(reps / dt, 4), "unit": unit, "cores": 1, "kind": "port",
                    "sample": f"{reps} of the 75 candidates on the full 1024x1024x7 stack ({dt:.1f} s), NumPy oracle, 1 thread"}
     scale_u = 1e6 if unit.startswith("M") else 1.0
-    line = {"metric": metric, "value": round(steps * units / elapsed / scale_u, 2), "unit": unit, "n_gpus": 1, "steps": steps, "warmup": warmup,
+    line = {"metric": metric, "value": round(world * steps * units / elapsed / scale_u, 2), "unit": unit, "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "achieved": round(alg / avg_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(alg / avg_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2), "note": bound_note},
-            "cpu_baseline": cpu}
+            "ranks": ranks, "cpu_baseline": cpu}
     print(json.dumps(line), flush=True)
 
 
@@ -337,12 +392,14 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the stack the CPU baseline merges (0 = per workload: 4096 val-only, 512 with std / corrections)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    late_imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if a.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -364,7 +421,7 @@ def main():
         torch.cuda.synchronize()
 
     if a.workload in ("welford", "energy"):          # single-GPU workloads with their own line
-        producer_workload(a, dev)
+        producer_workload(a, dev, rank, world, dist)
         return
     from camera_linearity_amd import engine
     from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
@@ -498,10 +555,7 @@ def main():
         for p_ in plans[:2]:                                       # restore the outputs the CPU leg will check
             p_.launch()
         torch.cuda.synchronize()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed, ranks = rank_report(dist, a, dev, elapsed, avg_us)
 
     # CPU leg + parity check of the timed configuration against the oracle on a row band (not timed on the GPU side)
     cpu = None
@@ -538,9 +592,10 @@ def main():
                          "isolated_launch_us_min_median": [round(float(np.min(kernel_us)), 2), round(float(np.median(kernel_us)), 2)],
                          "copy_GBps": None if copy_gbps is None else round(copy_gbps, 1),
                          "frac_of_copy": None if copy_gbps is None else round(achieved / copy_gbps, 4)},
+            "ranks": ranks,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -80,3 +80,28 @@ def test_row_tiles_three_ranks_on_gpu():
         assert p.exitcode == 0
     assert np.array_equal(gval, whole["val"].cpu().numpy())
     assert np.array_equal(gstd, whole["std"].cpu().numpy())
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg4"])
+def test_bench_launches_its_own_ranks(workload):
+    """`python bench.py --gpus 2 ...` from a plain shell (no torchrun on the command line): the parent starts its two ranks as a
+    child process (here both on the one GPU, gloo carrying the barrier) and rank 0's single JSON line comes through."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-device", "--dist-backend", "gloo", "--workload", workload,
+                          "--steps", "5", "--warmup", "1", "--prewarm-s", "0.05", "--stacks", "1"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["cpu_baseline"] is None
+    assert line["ranks"]["ranks_seen"] == 2 and len(line["ranks"]["avg_launch_us_per_rank"]) == 2
+    assert line["ranks"]["avg_launch_us_min"] <= line["ranks"]["avg_launch_us_max"]
+    assert line["roofline"]["kernel"].startswith("merge_u8_val3")

@@ -3,6 +3,7 @@ validation that needs no device, host-side logic (settings, file-name grammar, d
 row tiles, weight tables) and constructor/type errors modelled on the reference's
 tests/unit/test_measurand.py:120-167 and tests/unit/test_image_set.py:317-361."""
 import ctypes as C
+import os
 import pathlib
 import re
 
@@ -299,3 +300,60 @@ def test_merge_splits_huge_tiles_into_row_bands():
     assert all(p.startswith("merge_u8_val3") or p.startswith("merge_generic") for p in parts)
     rc, names = _describe(7, H=65538, W=21846, std=True, darks=True)
     assert rc == 0 and names.count("merge_u8_fast_std") == 2 and names.count("merge_fixup_hot") == 2
+
+
+# ---------------------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
+def test_bench_self_launch_spawns_ranks_before_touching_torch():
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) must start the ranks as a CHILD
+    `python -m torch.distributed.run ... bench.py <same arguments>` and return its exit code - before torch (and with it any HIP
+    call) is imported into the parent: a process that has initialised the GPU must never exec or fork workers on the pool's boxes."""
+    import pathlib
+    import subprocess
+    import sys
+    import textwrap
+    root = pathlib.Path(__file__).resolve().parent.parent
+    code = textwrap.dedent(f"""
+        import json, os, sys
+        sys.path.insert(0, {str(root)!r})
+        os.environ.pop("WORLD_SIZE", None)
+        import bench
+        assert "torch" not in sys.modules and "numpy" not in sys.modules, "bench.py imports torch at module level"
+        seen = {{}}
+        class R:
+            returncode = 42
+        def fake(cmd, env=None, **kw):
+            seen["cmd"], seen["torch_loaded"] = cmd, "torch" in sys.modules
+            seen["ipc"] = (env or {{}}).get("HSA_ENABLE_IPC_MODE_LEGACY")
+            return R()
+        bench.subprocess.run = fake
+        sys.argv = ["bench.py", "--gpus", "4", "--workload", "cfg4", "--steps", "3"]
+        try:
+            bench.main()
+        except SystemExit as e:
+            seen["rc"] = e.code
+        seen["torch_after"] = "torch" in sys.modules
+        print(json.dumps(seen))
+    """)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    import json
+    seen = json.loads(out.stdout.strip().splitlines()[-1])
+    cmd = seen["cmd"]
+    assert seen["rc"] == 42 and seen["torch_loaded"] is False and seen["torch_after"] is False
+    assert seen["ipc"] == "0"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = [i for i, c in enumerate(cmd) if c.endswith("bench.py")][0]
+    assert cmd[k + 1:] == ["--gpus", "4", "--workload", "cfg4", "--steps", "3"]
+
+
+def test_bench_does_not_self_launch_under_a_launcher():
+    """With WORLD_SIZE set (torch.distributed.run started us) main() goes on to initialise its rank instead of spawning again;
+    a mismatch between --gpus and the launcher's world size is an error, not a silent run."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
