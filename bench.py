@@ -123,10 +123,10 @@ def _kernel_key(name):
 
 
 def measured_traffic(workload, kernel=None):
-    """HBM bytes per launch from the PMC pass of THIS round's profile run (tools/profile.sh -> profiles/r02_pmc_traffic.json,
+    """HBM bytes per launch from the PMC pass of THIS round's profile run (tools/profile.sh -> profiles/r03_pmc_traffic.json,
     which records the commit, workload and kernel it was collected on); None when there is no such record for the workload or when
     it was taken on another kernel than the one this run launches."""
-    tp = ROOT / "profiles" / "r02_pmc_traffic.json"
+    tp = ROOT / "profiles" / "r03_pmc_traffic.json"
     if not tp.exists():
         return None, None
     try:
@@ -138,7 +138,7 @@ def measured_traffic(workload, kernel=None):
         return None, None
     if kernel is not None and _kernel_key(ent.get("kernel")) != _kernel_key(kernel.split(" + ")[0]):
         return None, None
-    return ent.get("hbm_bytes_per_launch"), f"profiles/r02_pmc_traffic.json ({ent.get('kernel', '?')} @ {ent.get('commit', '?')})"
+    return ent.get("hbm_bytes_per_launch"), f"profiles/r03_pmc_traffic.json ({ent.get('kernel', '?')} @ {ent.get('commit', '?')})"
 
 
 def cpu_leg(a, plan, stack, icrf, diff, rows, n, H, W, with_std, corr):
@@ -154,8 +154,7 @@ def cpu_leg(a, plan, stack, icrf, diff, rows, n, H, W, with_std, corr):
     sh = None if stack["stds"] is None else [host(s_) for s_ in stack["stds"]]
     kw = {}
     if hot:
-        dv = orc.unit_from_u8(host(stack["dark"]))
-        kw.update(darks=[dv] * n, dark_threshold=DARK_THR, median_k=3)
+        kw.update(darks=[orc.unit_from_u8(host(d)) for d in stack["darks"]], dark_threshold=DARK_THR, median_k=3)
     if flat_on:
         fk = stack["kw"]
         kw.update(flat=orc.unit_from_u8(host(stack["flat"])), flat_std=host(stack["flat_std"]), ff_mean=np.asarray(fk["ff_mean"]),
@@ -388,6 +387,9 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal only: initialise the process group even at world size 1")
     ap.add_argument("--hot-density", type=float, default=1e-4, help="fraction of hot elements in the synthetic dark maps (cfg3 / cfg3hot)")
+    ap.add_argument("--shared-dark", action="store_true", help="cfg3 / cfg3hot: ONE dark map shared by the 7 frames (round 2's setup: the map is read once and a hot "
+                                                               "element is hot in every frame) instead of one map per frame (SURVEY 8d: d * N bytes)")
+    ap.add_argument("--no-hot-queue", action="store_true", help="A/B: run the hot-pixel pass without its queue workspace (round 2's one-element-per-wave pass)")
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="seconds of untimed launches before the warm-up steps")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the stack the CPU baseline merges (0 = per workload: 4096 val-only, 512 with std / corrections)")
     a = ap.parse_args()
@@ -446,13 +448,16 @@ def main():
         extra = {}
         if corr:
             flat, flat_std, dark = synthetic_flat_dark(seed, H, W, device=dev, hot_density=a.hot_density)
-            extra.update(flat=flat, flat_std=flat_std, dark=dark)
+            darks = [dark] * n
+            if not a.shared_dark:            # one dark map per frame (the reference picks a dark frame per exposure, image_set.py:157-198)
+                darks = [dark] + [synthetic_flat_dark(seed + 17 * i, H, W, device=dev, hot_density=a.hot_density)[2] for i in range(1, n)]
+            extra.update(flat=flat, flat_std=flat_std, darks=darks)
             x0, x1, y0, y1 = engine.flat_roi_bounds(H, W, 0.2)
             if corr in (True, "flat"):
                 kw.update(flat=flat, flat_std=flat_std, ff_mean=engine.roi_mean(flat, x0, x1, y0, y1).cpu().numpy(),
                           ff_std_mean=engine.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy())
             if corr in (True, "hot"):
-                kw.update(darks=[dark] * n, dark_min=[engine.dark_min_dn(1.0, DARK_THR)] * n, median_k=3)
+                kw.update(darks=darks, dark_min=[engine.dark_min_dn(1.0, DARK_THR)] * n, median_k=3, hot_queue=not a.no_hot_queue)
         plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds, variant=a.variant, **kw)
         return plan, dict(frames=frames, stds=stds, t=t, kw=kw, **extra)
 
@@ -582,6 +587,8 @@ def main():
                                    + (f"; {len(plans)} distinct resident stacks merged round-robin (cold inputs)" if len(plans) > 1 and launches_per_step == 1 else ""),
                        "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3, "resident_stacks": len(plans),
                        "hot_density": a.hot_density if corr in (True, "hot") else None,
+                       "dark_maps": (("1 shared by the frames" if a.shared_dark else f"{n} distinct") + ("" if not a.no_hot_queue else ", no queue workspace"))
+                       if corr in (True, "hot") else None,
                        "parallelism": f"independent stacks x{world * max(launches_per_step, 1)} per step, no collective", "variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -43,6 +43,7 @@ class MergeArgs(C.Structure):
         ("flat_u8", C.c_void_p), ("flat_f64", C.c_void_p), ("flat_std", C.c_void_p),
         ("ff_mean", C.c_double * HM_MAX_CHANNELS), ("ff_std_mean", C.c_double * HM_MAX_CHANNELS),
         ("out_val", C.c_void_p), ("out_std", C.c_void_p), ("out_sum_w", C.c_void_p),
+        ("hot_workspace", C.c_void_p), ("hot_workspace_bytes", C.c_size_t),
     ]
 
 
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "hm_linearize_u8": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "hm_linearize_f64": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "hm_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
+    "hm_merge_hot_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "hm_merge_algorithmic_bytes": (C.c_int64, [C.POINTER(MergeArgs)]),
     "hm_merge_describe": (C.c_int, [C.POINTER(MergeArgs), C.c_char_p, C.c_int]),
     "hm_hot_pixel_filter_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,

@@ -83,5 +83,68 @@ __device__ __noinline__ T wave_median(const T* __restrict__ buf, int64_t H, int6
     return static_cast<T>(readlane_f64(v, src < 0 ? 0 : src));
 }
 
+// ------------------------------------------------------------------------------------------------
+// k x k median of one channel around one pixel computed by ONE LANE for its own pixel (every lane of a wave may
+// be at a different pixel): the shape of the queue-driven hot-pixel kernels, where every lane patches one hot
+// element. k = 3: nine loads and the 19-exchange median-of-9 network (min / max pairs; checked exhaustively on
+// 0/1 inputs). k = 5, 7: rank counting with the neighbourhood re-read from the cache for every candidate
+// (k^4 loads worst case - rare kernel sizes; no 49-entry register array). Same order statistic as wave_median().
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct MedianKey;
+template <> struct MedianKey<uint8_t> {
+    using type = uint32_t;
+    static __device__ __forceinline__ uint32_t lo(uint32_t a, uint32_t b) { return a < b ? a : b; }
+    static __device__ __forceinline__ uint32_t hi(uint32_t a, uint32_t b) { return a < b ? b : a; }
+};
+template <> struct MedianKey<double> {
+    using type = double;
+    static __device__ __forceinline__ double lo(double a, double b) { return a < b ? a : b; }
+    static __device__ __forceinline__ double hi(double a, double b) { return a < b ? b : a; }
+};
+
+// median of nine values in registers: the 19-exchange network
+template <typename T>
+__device__ __forceinline__ typename MedianKey<T>::type median9(typename MedianKey<T>::type (&p)[9]) {
+    using K = MedianKey<T>;
+    using V = typename K::type;
+#define HM_CX(a, b) { const V lo_ = K::lo(p[a], p[b]); const V hi_ = K::hi(p[a], p[b]); p[a] = lo_; p[b] = hi_; }
+    HM_CX(1, 2) HM_CX(4, 5) HM_CX(7, 8) HM_CX(0, 1) HM_CX(3, 4) HM_CX(6, 7) HM_CX(1, 2) HM_CX(4, 5) HM_CX(7, 8)
+    HM_CX(0, 3) HM_CX(5, 8) HM_CX(4, 7) HM_CX(3, 6) HM_CX(1, 4) HM_CX(2, 5) HM_CX(4, 7) HM_CX(4, 2) HM_CX(6, 4) HM_CX(4, 2)
+#undef HM_CX
+    return p[4];
+}
+
+template <typename T>
+__device__ __forceinline__ T lane_median(const T* __restrict__ buf, int64_t H, int64_t W, int C,
+                                         int64_t buf_row0, int64_t row, int64_t col, int c, int k) {
+    using K = MedianKey<T>;
+    using V = typename K::type;
+    if (k == 3) {
+        const int64_t y[3] = {(reflect_index(row - 1, H) - buf_row0) * W, (row - buf_row0) * W, (reflect_index(row + 1, H) - buf_row0) * W};
+        const int64_t x[3] = {reflect_index(col - 1, W), col, reflect_index(col + 1, W)};
+        V p[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p[q] = static_cast<V>(buf[(y[q / 3] + x[q % 3]) * C + c]);
+        return static_cast<T>(median9<T>(p));
+    }
+    const int n = k * k, r = k / 2, m = n / 2;
+    auto at = [&](int q) -> V {
+        const int64_t yy = reflect_index(row + (q / k - r), H) - buf_row0;
+        const int64_t xx = reflect_index(col + (q % k - r), W);
+        return static_cast<V>(buf[(yy * W + xx) * C + c]);
+    };
+    V med = at(m);
+    for (int q = 0; q < n; ++q) {
+        const V v = at(q);
+        int less = 0, leq = 0;
+        for (int s = 0; s < n; ++s) {
+            const V u = at(s);
+            less += (u < v);
+            leq += (u <= v);
+        }
+        if (less <= m && m < leq) { med = v; break; }
+    }
+    return static_cast<T>(med);
+}
 
 }  // namespace hm

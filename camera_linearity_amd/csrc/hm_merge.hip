@@ -25,6 +25,7 @@
 //                     d*N term of the algorithmic byte count.
 #include "hm_common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <type_traits>
 
@@ -98,28 +99,35 @@ __device__ __forceinline__ void flat_field_apply(const MergeK& a, int64_t e, int
 // shared by every kernel of this file, so a result does not depend on which kernel (or tiling) produced
 // it: S = sum_i w_i in frame order; 1/S and 1/S**2 formed once; the numerator of :388 accumulated with
 // fma and divided by S at the end; variance terms of :389 accumulated with fma.
-// COOP = false: plain per-thread evaluation, dark maps ignored (streaming kernels).
-// COOP = true : `e` is wave-uniform, every lane evaluates the same element and hot frames take their value
-//               from wave_median(); `store` selects the one lane that writes.
+// HOT = HOT_NONE: plain per-thread evaluation, dark maps ignored (streaming kernels).
+// HOT = HOT_WAVE: `e` is wave-uniform, every lane evaluates the same element and hot frames take their value
+//                 from wave_median(); `store` selects the one lane that writes.
+// HOT = HOT_LANE: every lane evaluates its OWN element and takes the medians of its hot frames itself
+//                 (lane_median(); the queue-driven patch kernel).
 // Tables: t_w/t_dw [256], t_g/t_d [256*C] in LDS.
 // ------------------------------------------------------------------------------------------------
-template <bool F64IN, bool STD, bool COOP>
+enum { HOT_NONE = 0, HOT_WAVE = 1, HOT_LANE = 2 };
+template <bool F64IN, bool STD, int HOT>
 __device__ __forceinline__ void merge_one_element(const MergeK& a, const double* t_w, const double* t_dw,
                                                   const double* t_g, const double* t_d, int64_t e, bool store) {
     const int C = a.C, N = a.n_frames;
     const int64_t ei = a.in_off + e;
     const int c = static_cast<int>(e % C);
     int64_t row = 0, col = 0; int cc = 0;
-    if (COOP) elem_to_pixel(a, e, row, col, cc);
-    auto is_hot = [&](int i) -> bool { return COOP && a.dark[i] && static_cast<int>(a.dark[i][ei]) >= a.dark_min[i]; };
+    if (HOT != HOT_NONE) elem_to_pixel(a, e, row, col, cc);
+    auto is_hot = [&](int i) -> bool { return HOT != HOT_NONE && a.dark[i] && static_cast<int>(a.dark[i][ei]) >= a.dark_min[i]; };
+    auto median_of = [&](auto* f) {
+        if constexpr (HOT == HOT_WAVE) return wave_median(f, a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+        else return lane_median(f, a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+    };
     auto value_f64 = [&](int i, bool hot) -> double {
         const double* f = static_cast<const double*>(a.frame[i]);
-        if (COOP && hot) return wave_median(f, a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+        if (HOT != HOT_NONE && hot) return median_of(f);
         return f[ei];
     };
     auto value_u8 = [&](int i, bool hot) -> uint32_t {
         const uint8_t* f = static_cast<const uint8_t*>(a.frame[i]);
-        if (COOP && hot) return wave_median(f, a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+        if (HOT != HOT_NONE && hot) return median_of(f);
         return f[ei];
     };
     // ---- pass 1: S = sum_i w_i (exposure_series.py:340) ----
@@ -162,7 +170,7 @@ __device__ __forceinline__ void merge_one_element(const MergeK& a, const double*
         acc = (i == 0) ? wg * it : fma(wg, it, acc);                    // :388 numerator
         if (STD) {
             double s;
-            if (COOP && hot) s = wave_median(a.sd[i], a.H, a.W, C, a.buf_row0, row, col, cc, a.median_k);
+            if (HOT != HOT_NONE && hot) s = median_of(a.sd[i]);
             else s = a.sd[i][ei];
             const double dg = t_d[idx * C + c] * s;                     // measurand.py:512
             const double A = (dw * g + w * dg) * invS - ((dw * w) * g) * invS2;   // :389
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void merge_generic(const MergeK a) {
     __syncthreads();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < a.n_elems; q += stride)
-        merge_one_element<F64IN, STD, false>(a, t_w, t_dw, t_g, t_d, a.elem0 + q, true);
+        merge_one_element<F64IN, STD, HOT_NONE>(a, t_w, t_dw, t_g, t_d, a.elem0 + q, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,8 +347,38 @@ __device__ __forceinline__ void fixup_element(const MergeK& a, const double* t_w
     }
 }
 
-// merge_fixup_hot: every lane scans 16 consecutive elements of every distinct dark map (one 16-byte load
-// when the address allows); elements with at least one hot frame are recomputed, one at a time, by the wave.
+// hot bits of the lane's 16-element chunk: bit b set iff element e0 + b is hot in at least one frame. Every DISTINCT
+// (dark map, threshold) is read once - one 16-byte load when the address allows (the d * N term of the algorithmic bytes).
+__device__ __forceinline__ uint32_t scan_chunk_hotbits(const MergeK& a, int64_t e0, int cnt) {
+    uint32_t hotbits = 0;
+    for (int i = 0; i < a.n_frames; ++i) {
+        const uint8_t* d = a.dark[i];
+        if (!d) continue;
+        bool seen = false;                                          // same map + threshold as an earlier frame
+        for (int k = 0; k < i; ++k) seen = seen || (a.dark[k] == d && a.dark_min[k] == a.dark_min[i]);
+        if (seen) continue;
+        const uint8_t* p = d + a.in_off + e0;
+        const uint32_t thr = static_cast<uint32_t>(a.dark_min[i]);
+        if (cnt == 16 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; ++b) hotbits |= (((w4[b >> 2] >> (8 * (b & 3))) & 255u) >= thr) ? (1u << b) : 0u;
+        } else {
+            for (int b = 0; b < cnt; ++b) hotbits |= (static_cast<uint32_t>(p[b]) >= thr) ? (1u << b) : 0u;
+        }
+    }
+    return hotbits;
+}
+
+// Hot-element queue in the caller's workspace (hm_merge_args.hot_workspace): two counters, then the element indices.
+//   ws[0] = number of queued elements, ws[1] = overflow flag (the queue was too small: merge_patch_hot goes over the whole tile),
+//   ws[4 ...] = element indices relative to row0 (uint32: the queue path requires fewer than 2^32 elements per call).
+constexpr int kHotQueueHeader = 4;       // uint32 words before the first queue entry (16 bytes)
+
+// merge_fixup_hot: every lane scans 16 consecutive elements of every distinct dark map; elements with at least one hot
+// frame are recomputed, one at a time, by the wave. This is the path WITHOUT a workspace: one element per wave at a time
+// makes it collapse on dense maps (15 us of one wave per hot element) - callers that can pass a workspace should.
 template <bool F64IN, bool STD>
 __global__ __launch_bounds__(256) void merge_fixup_hot(const MergeK a) {
     __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
@@ -357,24 +395,7 @@ __global__ __launch_bounds__(256) void merge_fixup_hot(const MergeK a) {
         uint32_t hotbits = 0;
         if (chunk < n_chunks) {
             const int64_t left = a.elem0 + a.n_elems - e0;
-            const int cnt = left < 16 ? static_cast<int>(left) : 16;
-            for (int i = 0; i < a.n_frames; ++i) {
-                const uint8_t* d = a.dark[i];
-                if (!d) continue;
-                bool seen = false;                                          // same map + threshold as an earlier frame
-                for (int k = 0; k < i; ++k) seen = seen || (a.dark[k] == d && a.dark_min[k] == a.dark_min[i]);
-                if (seen) continue;
-                const uint8_t* p = d + a.in_off + e0;
-                const uint32_t thr = static_cast<uint32_t>(a.dark_min[i]);
-                if (cnt == 16 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-                    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int b = 0; b < 16; ++b) hotbits |= (((w4[b >> 2] >> (8 * (b & 3))) & 255u) >= thr) ? (1u << b) : 0u;
-                } else {
-                    for (int b = 0; b < cnt; ++b) hotbits |= (static_cast<uint32_t>(p[b]) >= thr) ? (1u << b) : 0u;
-                }
-            }
+            hotbits = scan_chunk_hotbits(a, e0, left < 16 ? static_cast<int>(left) : 16);
         }
         unsigned long long pending = __ballot(hotbits != 0);
         while (pending) {                                                    // rare
@@ -388,6 +409,329 @@ __global__ __launch_bounds__(256) void merge_fixup_hot(const MergeK a) {
                 fixup_element<F64IN, STD>(a, t_w, t_dw, t_g, t_d, base + b);
             }
         }
+    }
+}
+
+// merge_scan_hot: the scan alone. A wave scans kScanRound spans of 1024 elements per round (16 bytes per lane, map and span: up to
+// 8 x #maps loads in flight per lane), the workgroup's 16 waves add up their counts through LDS and ONE atomic add per workgroup
+// and round reserves its piece of the queue (an atomic per wave and span serialised on the counter: 49 000 returning atomics on
+// one address took 365 us at a density of 1e-3, profiles/r03c_hot_trace.txt). Every wave runs the same number of rounds (barriers).
+// The order of the pieces in the queue depends on the order of the atomics; the patched image does not (every queued element is
+// recomputed independently).
+constexpr int kScanRound = 4;
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uint32_t* ws, uint32_t capacity) {
+    __shared__ uint32_t s_tot[kScanBlock / 64];
+    __shared__ uint32_t s_base, s_ok;
+    constexpr uint32_t WPB = kScanBlock / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n_chunks = (a.n_elems + 15) / 16;
+    const int64_t n_spans = (n_chunks + 63) / 64;
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * WPB;
+    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * WPB + wave;
+    const int64_t rounds = (n_spans + n_waves * kScanRound - 1) / (n_waves * kScanRound);
+    // distinct (map, threshold) pairs: bit i set = frame i's map is read (wave-uniform, once); `wide` = every such map can be read with
+    // aligned 16-byte loads (its pointer + in_off is 16-byte aligned: elem0 and the chunk starts are multiples of 16)
+    uint32_t distinct = 0;
+    bool wide = (a.elem0 & 15) == 0;
+    for (int i = 0; i < a.n_frames; ++i) {
+        const uint8_t* d = a.dark[i];
+        if (!d) continue;
+        bool seen = false;
+        for (int k = 0; k < i; ++k) seen = seen || (a.dark[k] == d && a.dark_min[k] == a.dark_min[i]);
+        if (seen) continue;
+        distinct |= 1u << i;
+        wide = wide && (reinterpret_cast<uintptr_t>(d + a.in_off) & 15) == 0;
+    }
+    const int64_t n_full = a.n_elems / 16;                                  // whole 16-element chunks; a last partial one goes the slow way
+    for (int64_t r = 0; r < rounds; ++r) {
+        uint32_t hb[kScanRound];
+        uint32_t mine = 0;
+        if (wide) {
+            // no load sits behind a lane-dependent branch: the kScanRound loads of a map are issued back to back (a chunk past the end
+            // re-reads chunk 0 and is masked afterwards), then compared
+            int64_t off[kScanRound];
+            bool valid[kScanRound];
+#pragma unroll
+            for (int k = 0; k < kScanRound; ++k) {
+                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                valid[k] = chunk < n_full;
+                off[k] = a.in_off + a.elem0 + (valid[k] ? chunk : 0) * 16;
+                hb[k] = 0;
+            }
+            if (n_full > 0) {
+                for (uint32_t left = distinct; left; left &= left - 1) {    // wave-uniform loop over the distinct maps
+                    const int i = __builtin_amdgcn_readfirstlane(__ffs(static_cast<int>(left)) - 1);
+                    const uint8_t* d = a.dark[i];
+                    const uint32_t thr = static_cast<uint32_t>(a.dark_min[i]);
+                    u32x4 v[kScanRound];
+#pragma unroll
+                    for (int k = 0; k < kScanRound; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(d + off[k]));
+#pragma unroll
+                    for (int k = 0; k < kScanRound; ++k) {
+                        const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                        for (int b = 0; b < 16; ++b) hb[k] |= (((w4[b >> 2] >> (8 * (b & 3))) & 255u) >= thr) ? (1u << b) : 0u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kScanRound; ++k) {
+                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                if (!valid[k]) hb[k] = 0;
+                if (chunk == n_full && chunk < n_chunks)                    // the tile's last, partial chunk (one lane of one wave)
+                    hb[k] = scan_chunk_hotbits(a, a.elem0 + chunk * 16, static_cast<int>(a.n_elems - chunk * 16));
+                mine += static_cast<uint32_t>(__popc(hb[k]));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanRound; ++k) {
+                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                hb[k] = 0;
+                if (chunk < n_chunks) {
+                    const int64_t e0 = a.elem0 + chunk * 16;
+                    const int64_t left = a.elem0 + a.n_elems - e0;
+                    hb[k] = scan_chunk_hotbits(a, e0, left < 16 ? static_cast<int>(left) : 16);
+                }
+                mine += static_cast<uint32_t>(__popc(hb[k]));
+            }
+        }
+        uint32_t incl = mine;                                               // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= static_cast<uint32_t>(d)) incl += up;
+        }
+        if (lane == 63u) s_tot[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < WPB; ++w) total += s_tot[w];
+            uint32_t base = 0, ok = 1;
+            if (total) {
+                base = atomicAdd(&ws[0], total);
+                if (base + total > capacity || base + total < base) {       // queue full: flag it, merge_patch_hot goes over the whole tile instead
+                    atomicOr(&ws[1], 1u);
+                    ok = 0;
+                }
+            }
+            s_base = base; s_ok = ok;
+        }
+        __syncthreads();
+        if (s_ok && mine) {
+            uint32_t off = s_base + (incl - mine);
+            for (uint32_t w = 0; w < wave; ++w) off += s_tot[w];
+            uint32_t* q = ws + kHotQueueHeader + off;
+#pragma unroll
+            for (int k = 0; k < kScanRound; ++k) {
+                uint32_t bits = hb[k];
+                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                const uint32_t first = static_cast<uint32_t>(a.elem0 + chunk * 16);   // < 2^32 (host check)
+                while (bits) {
+                    const int b = __ffs(static_cast<int>(bits)) - 1;
+                    bits &= bits - 1;
+                    *q++ = first + static_cast<uint32_t>(b);
+                }
+            }
+        }
+        __syncthreads();                                                    // s_tot / s_base are rewritten in the next round
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-LANE hot-pixel patch: every lane recomputes its own hot element, so up to 64 elements are in flight per wave and their
+// memory round trips overlap. patch_element_k3() is merge_one_element()'s operation sequence written so that the dependent
+// rounds are few: the dark bytes of 8 frames at a time, then - for kPatchFB frames at a time - ALL nine neighbours of every frame
+// with select-ed addresses (a frame that is not hot reads its own element nine times: no branch sits between the loads and
+// the compiler's wait counts stay exact), the 19-exchange median network, and the frames' arithmetic in frame order.
+// Pass 1 leaves every frame's (filtered) value in a per-thread LDS column for pass 2; the std medians are taken in pass 2.
+// Other kernel sizes (5, 7) and float64 stacks of more than kPatchF64Frames frames go through merge_one_element<HOT_LANE>.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPatchFB = 4;             // frames whose nine neighbour loads are issued together (float64 values / stds)
+constexpr int kPatchFBU8 = 8;           // the same for uint8 values (one VGPR each)
+constexpr int kPatchF64Frames = 16;     // float64 stacks: frames kept in LDS between the passes (8 B x 256 threads each)
+
+__device__ __forceinline__ uint32_t lane_hotmask(const MergeK& a, int64_t ei) {
+    uint32_t hotmask = 0;
+    const int N = a.n_frames;
+    for (int i0 = 0; i0 < N; i0 += 8) {
+        uint32_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            d[k] = 0;
+            if (i0 + k < N && a.dark[i0 + k]) d[k] = a.dark[i0 + k][ei];                 // wave-uniform condition
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k < N && a.dark[i0 + k]) hotmask |= (static_cast<int>(d[k]) >= a.dark_min[i0 + k]) ? (1u << (i0 + k)) : 0u;
+    }
+    return hotmask;
+}
+
+template <bool F64IN, bool STD>
+__device__ __forceinline__ void patch_element_k3(const MergeK& a, const double* t_w, const double* t_dw, const double* t_g, const double* t_d,
+                                                 std::conditional_t<F64IN, double, uint8_t>* keep /* LDS, this thread's column, stride 256 */,
+                                                 int64_t e, uint32_t hotmask) {
+    using T = std::conditional_t<F64IN, double, uint8_t>;
+    using V = typename MedianKey<T>::type;
+    const int C = a.C, N = a.n_frames;
+    const int64_t ei = a.in_off + e;
+    const int c = static_cast<int>(e % C);
+    int64_t row, col; int cc;
+    elem_to_pixel(a, e, row, col, cc);
+    const int64_t wc = a.W * C;
+    const int64_t dy[3] = {(reflect_index(row - 1, a.H) - row) * wc, 0, (reflect_index(row + 1, a.H) - row) * wc};
+    const int64_t dx[3] = {(reflect_index(col - 1, a.W) - col) * C, 0, (reflect_index(col + 1, a.W) - col) * C};
+    // ---- pass 1: filtered values, S = sum_i w_i (exposure_series.py:340)
+    constexpr int FBV = F64IN ? kPatchFB : kPatchFBU8;
+    double S = 0.0;
+    for (int i0 = 0; i0 < N; i0 += FBV) {
+        V p[FBV][9];
+#pragma unroll
+        for (int f = 0; f < FBV; ++f) {
+            if (i0 + f < N) {
+                const T* fr = static_cast<const T*>(a.frame[i0 + f]) + ei;
+                const bool hot = (hotmask >> (i0 + f)) & 1u;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) p[f][q] = static_cast<V>(fr[hot ? dy[q / 3] + dx[q % 3] : int64_t{0}]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FBV; ++f) {
+            if (i0 + f < N) {
+                const V v = median9<T>(p[f]);
+                keep[(i0 + f) * 256] = static_cast<T>(v);
+                double w;
+                if constexpr (F64IN) w = gauss_weight(v - 0.5);                          // measurand.py:615
+                else w = t_w[v];
+                S = (i0 + f == 0) ? w : S + w;
+            }
+        }
+    }
+    if (a.out_sum_w) a.out_sum_w[e] = S;
+    if (!a.out_val) return;
+    const double invS = 1.0 / S;
+    const double invS2 = 1.0 / (S * S);                                                  // 1 / S**2, exposure_series.py:343
+    // ---- pass 2: exposure_series.py:382-389
+    double acc = 0.0, var = 0.0;
+    for (int i0 = 0; i0 < N; i0 += kPatchFB) {
+        double sp[STD ? kPatchFB : 1][9];
+        if constexpr (STD) {
+#pragma unroll
+            for (int f = 0; f < kPatchFB; ++f) {
+                if (i0 + f < N) {
+                    const double* sr = a.sd[i0 + f] + ei;
+                    const bool hot = (hotmask >> (i0 + f)) & 1u;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sp[f][q] = sr[hot ? dy[q / 3] + dx[q % 3] : int64_t{0}];
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < kPatchFB; ++f) {
+            if (i0 + f < N) {
+                const int i = i0 + f;
+                double w, dw;
+                uint32_t idx;
+                if constexpr (F64IN) {
+                    const double v = keep[i * 256];
+                    const double dv = v - 0.5;
+                    w = gauss_weight(dv);
+                    dw = (-60.0 * dv) * w;                                               // measurand.py:616
+                    idx = static_cast<uint32_t>(static_cast<int64_t>(rint(v * 255.0))) & 255u;   // measurand.py:503
+                } else {
+                    idx = keep[i * 256];
+                    w = t_w[idx];
+                    dw = STD ? t_dw[idx] : 0.0;
+                }
+                const double g = t_g[idx * C + c];
+                const double it = a.inv_t[i];
+                const double wg = w * g;
+                acc = (i == 0) ? wg * it : fma(wg, it, acc);                             // :388 numerator
+                if constexpr (STD) {
+                    const double sv = median9<double>(sp[f]);
+                    const double dg = t_d[idx * C + c] * sv;                             // measurand.py:512
+                    const double A = (dw * g + w * dg) * invS - ((dw * w) * g) * invS2;  // :389
+                    const double term = (A * dg) * it;
+                    var = (i == 0) ? term * term : fma(term, term, var);
+                }
+            }
+        }
+    }
+    double val = acc / S;
+    double sd = STD ? sqrt(var) : 0.0;                                                   // :394
+    if (a.has_flat) flat_field_apply(a, e, c, STD, val, sd);
+    a.out_val[e] = val;
+    if (STD) a.out_std[e] = sd;
+}
+
+template <bool F64IN, bool STD>
+__device__ __forceinline__ void patch_element(const MergeK& a, const double* t_w, const double* t_dw, const double* t_g, const double* t_d,
+                                              char* keep_lds, int64_t e, uint32_t hotmask) {
+    using T = std::conditional_t<F64IN, double, uint8_t>;
+    if (a.median_k == 3 && (!F64IN || a.n_frames <= kPatchF64Frames))                    // wave-uniform
+        patch_element_k3<F64IN, STD>(a, t_w, t_dw, t_g, t_d, reinterpret_cast<T*>(keep_lds) + threadIdx.x, e, hotmask);
+    else
+        merge_one_element<F64IN, STD, HOT_LANE>(a, t_w, t_dw, t_g, t_d, e, true);
+}
+static int patch_keep_bytes(bool f64in, int n_frames, int median_k) {
+    if (median_k != 3 || (f64in && n_frames > kPatchF64Frames)) return 16;
+    return n_frames * 256 * (f64in ? 8 : 1);
+}
+
+// merge_patch_hot: the queue's elements, one per lane. The grid is fixed (the host does not know the count), so the entries are
+// dealt to ALL its waves in blocks of B = ceil(count / waves) <= 64 consecutive entries: a short queue is spread over the
+// whole chip (one or a few active lanes per wave: the latency of one element, not of 64), a long one fills the waves (and
+// consecutive lanes take consecutive entries, which a wave's span put there in element order, so neighbouring lanes touch
+// neighbouring cache lines). Workgroups beyond the queue leave before they build their tables.
+// If the scan raised the overflow flag (more hot elements than the workspace holds: a quarter of the image with the recommended
+// size) the queue is ignored: every lane looks at its own elements' dark bytes and patches the hot ones.
+template <bool F64IN, bool STD>
+__global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uint32_t* ws) {
+    __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
+    extern __shared__ __attribute__((aligned(16))) char keep_lds[];
+    const uint32_t count = __builtin_amdgcn_readfirstlane(ws[0]);
+    const uint32_t overflow = __builtin_amdgcn_readfirstlane(ws[1]);
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t B = (count + n_waves - 1u) / n_waves;
+    B = B > 64u ? 64u : B;
+    if (overflow == 0u && (count == 0u || blockIdx.x * 4u * B >= count)) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    // the first entry and its dark bytes are fetched while the workgroup builds its tables (a short queue is one entry per lane:
+    // its latency is the kernel's duration)
+    int64_t e_first = 0;
+    uint32_t hot_first = 0;
+    if (overflow == 0u && lane < B && static_cast<uint64_t>(wave_id) * B + lane < count) {
+        e_first = static_cast<int64_t>(ws[kHotQueueHeader + static_cast<uint64_t>(wave_id) * B + lane]);
+        hot_first = lane_hotmask(a, a.in_off + e_first);
+    }
+    fill_plain_tables<F64IN, STD>(a, t_w, t_dw, t_g, t_d);
+    __syncthreads();
+    if (overflow != 0u) {
+        const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+        for (int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; q < a.n_elems; q += stride) {
+            const int64_t e = a.elem0 + q;
+            const uint32_t hotmask = lane_hotmask(a, a.in_off + e);
+            if (hotmask) patch_element<F64IN, STD>(a, t_w, t_dw, t_g, t_d, keep_lds, e, hotmask);
+        }
+        return;
+    }
+    bool first = true;
+    for (uint64_t base = static_cast<uint64_t>(wave_id) * B; base < count; base += static_cast<uint64_t>(n_waves) * B) {
+        const uint64_t q = base + lane;
+        if (lane < B && q < count) {
+            int64_t e = e_first;
+            uint32_t hotmask = hot_first;
+            if (!first) {
+                e = static_cast<int64_t>(ws[kHotQueueHeader + q]);
+                hotmask = lane_hotmask(a, a.in_off + e);
+            }
+            patch_element<F64IN, STD>(a, t_w, t_dw, t_g, t_d, keep_lds, e, hotmask);
+        }
+        first = false;
     }
 }
 
@@ -1416,6 +1760,12 @@ static bool describe_only(const char* fmt, int a = 0, int b = 0, int c = 0, int 
     return true;
 }
 
+// experiment knobs read from the environment (tools/ A/B scripts; unset in production): 0 = not set
+static int tune_env(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
 static int g_cu_count = 0;
 int cu_count() {
     if (g_cu_count == 0) {
@@ -1469,6 +1819,7 @@ static int launch_one(const MergeK& k, hipStream_t st) {
     if (describe_only(STD ? "merge_u8_fast_std<N=%d,U=%d,flat=%d,sum_w=%d>" : "merge_u8_fast<N=%d,U=%d,flat=%d,sum_w=%d>", NF, U, FLAT, SUMW)) return HM_OK;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
+    if (const int e = tune_env("HM_TUNE_WG_PER_CU")) per_cu = e;
     const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
     const unsigned grid = stream_grid(groups, BLOCK / 64, per_cu);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, st, k);
@@ -1712,6 +2063,31 @@ static int launch_fixup(const MergeK& k, bool f64in, bool with_std, hipStream_t 
     return launch_status();
 }
 
+// the queue path of the hot-pixel pass: zero the counters, scan the dark maps into the queue, patch the queued elements;
+// on overflow merge_patch_hot goes over the whole tile instead of the queue (a queue that was too small costs time, never correctness)
+static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t words = ws_bytes / 4;
+    const uint32_t capacity = static_cast<uint32_t>(words - kHotQueueHeader > 0xffffffffull ? 0xffffffffull : words - kHotQueueHeader);
+    if (describe_only("merge_scan_hot")) {
+        describe_only("merge_patch_hot<f64in=%d,std=%d>", f64in, with_std);
+        return HM_OK;
+    }
+    if (hipMemsetAsync(ws, 0, kHotQueueHeader * 4, st) != hipSuccess) return HM_ELAUNCH;
+    const int64_t chunks = (k.n_elems + 15) / 16;
+    hipLaunchKernelGGL(merge_scan_hot, dim3(stream_grid(chunks, kScanBlock, 1)), dim3(kScanBlock), 0, st, k, ws, capacity);
+    int rc = launch_status();
+    if (rc != HM_OK) return rc;
+    const unsigned grid = stream_grid(k.n_elems, 256, 8);
+    const int keep = patch_keep_bytes(f64in, k.n_frames, k.median_k);
+#define HM_PATCH(K, F, S) hipLaunchKernelGGL((K<F, S>), dim3(grid), dim3(256), keep, st, k, static_cast<const uint32_t*>(ws))
+#define HM_PATCH4(K) { if (f64in) { if (with_std) HM_PATCH(K, true, true); else HM_PATCH(K, true, false); } \
+                       else       { if (with_std) HM_PATCH(K, false, true); else HM_PATCH(K, false, false); } }
+    HM_PATCH4(merge_patch_hot)
+#undef HM_PATCH4
+#undef HM_PATCH
+    return launch_status();
+}
+
 }  // namespace hm
 
 extern "C" int64_t hm_merge_algorithmic_bytes(const hm_merge_args* g) {
@@ -1724,9 +2100,25 @@ extern "C" int64_t hm_merge_algorithmic_bytes(const hm_merge_args* g) {
     if (g->out_val) per += 8 * (1 + (s ? 1 : 0));
     if (g->out_sum_w) per += 8;
     if (g->flat_u8 || g->flat_f64) per += (g->flat_u8 ? 1 : 8) + ((s && g->flat_std) ? 8 : 0);
-    if (g->darks_u8)
-        for (int i = 0; i < N; ++i) per += g->darks_u8[i] ? 1 : 0;
+    if (g->darks_u8)                                       // every DISTINCT (map, threshold) is read once (scan_chunk_hotbits)
+        for (int i = 0; i < N; ++i) {
+            if (!g->darks_u8[i]) continue;
+            bool seen = false;
+            for (int k = 0; k < i; ++k)
+                seen = seen || (g->darks_u8[k] == g->darks_u8[i] && (!g->dark_min_dn || g->dark_min_dn[k] == g->dark_min_dn[i]));
+            per += seen ? 0 : 1;
+        }
     return per * E;
+}
+
+// Workspace of the hot-pixel queue for a call that produces n_elems = rows * W * C output elements: 16 bytes of counters +
+// one uint32 per queued element. The recommended size holds a quarter of the elements (a dark map with 25 % hot pixels);
+// any size from hm_merge_hot_workspace_bytes(1) up is accepted - a queue that overflows makes the patch kernel go over the whole tile.
+extern "C" size_t hm_merge_hot_workspace_bytes(int64_t n_elems) {
+    if (n_elems < 1) n_elems = 1;
+    int64_t entries = n_elems / 4;
+    if (entries < 4096) entries = n_elems < 4096 ? n_elems : 4096;
+    return static_cast<size_t>(hm::kHotQueueHeader + entries) * 4;
 }
 
 extern "C" int hm_merge_describe(const hm_merge_args* g, char* buf, int buf_len) {
@@ -1883,6 +2275,11 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     }
     if (rc != HM_OK) return rc;
     // ---- hot-pixel fix-up pass (stream-ordered after the streaming pass: it overwrites the affected elements)
-    if (hot) rc = launch_fixup(k, f64in, with_std, st);
+    if (hot) {
+        const bool queue = g->hot_workspace && g->hot_workspace_bytes >= hm_merge_hot_workspace_bytes(1) && aligned(g->hot_workspace, 16) &&
+                           E < (int64_t{1} << 32);
+        rc = queue ? launch_hot_queue(k, f64in, with_std, static_cast<uint32_t*>(g->hot_workspace), g->hot_workspace_bytes, st)
+                   : launch_fixup(k, f64in, with_std, st);
+    }
     return rc;
 }

@@ -278,14 +278,16 @@ def plan_merge(frames: Sequence[torch.Tensor], exposures: Sequence[float], icrf,
                flat: Optional[torch.Tensor] = None, flat_std: Optional[torch.Tensor] = None,
                ff_mean=None, ff_std_mean=None, want_sum_w: bool = False, want_val: bool = True,
                height: Optional[int] = None, row0: int = 0, rows: Optional[int] = None, buf_row0: int = 0,
-               variant: int = 0) -> MergePlan:
+               variant: int = 0, hot_queue: bool = True) -> MergePlan:
     """Build the launch descriptor for one fused merge (modules/exposure_series.py:317-419).
 
     frames : N tensors (buf_rows, W, C), all uint8 DNs or all float64 values, ascending exposure.
              They cover image rows [buf_row0, buf_row0 + buf_rows) of an image `height` rows tall;
              the call produces rows [row0, row0 + rows). Defaults: the buffers are the whole image.
     darks  : per frame a uint8 dark DN map covering the same rows as the frames, or None;
-             dark_min[i] = smallest hot DN (see dark_min_dn()).
+             dark_min[i] = smallest hot DN (see dark_min_dn()). hot_queue: give the hot-pixel pass its queue workspace
+             (hm_merge_hot_workspace_bytes: 1 byte per output element) so that it stays balanced on dense maps;
+             False = the workspace-free path (one hot element per wave at a time; sparse maps only).
     flat, flat_std : flat-field value (uint8 DN or float64) and float64 uncertainty covering the
              OUTPUT rows; ff_mean / ff_std_mean are the C ROI means (host floats).
     """
@@ -375,6 +377,11 @@ def plan_merge(frames: Sequence[torch.Tensor], exposures: Sequence[float], icrf,
         a.dark_min_dn = C.cast(dmin, C.POINTER(C.c_int32))
         a.median_k = int(median_k)
         keep += [dk, dptrs, dmin]
+        if hot_queue:
+            ws_bytes = int(nat.lib.hm_merge_hot_workspace_bytes(rows * W * Cc))
+            ws = torch.empty(ws_bytes, dtype=_U8, device=dev)          # torch allocations are 512-byte aligned
+            a.hot_workspace, a.hot_workspace_bytes = ws.data_ptr(), ws_bytes
+            keep.append(ws)
     out_shape = (rows, W, Cc)
     if flat is not None:
         _require_cuda(flat, "flat")

@@ -260,6 +260,70 @@ def test_hot_pixel_fixup_batches(eng, n, k, f64):
     out = eng.merge([dev(f) for f in frames], t, icrf, diff, darks=darks, dark_min=mins, median_k=k, want_sum_w=True)
     close(host(out["val"]), ref["val"], F64_RTOL if f64 else VAL_RTOL)
     close(host(out["sum_w"]), ref["S"], 1e-13)
+    # the workspace-free pass (one hot element per wave at a time) and the queue pass (one per lane) give the same bits
+    for kw in (dict(stds=[dev(s) for s in stds]), dict(want_sum_w=True)):
+        a_ = eng.merge([dev(f) for f in frames], t, icrf, diff, darks=darks, dark_min=mins, median_k=k, hot_queue=True, **kw)
+        b_ = eng.merge([dev(f) for f in frames], t, icrf, diff, darks=darks, dark_min=mins, median_k=k, hot_queue=False, **kw)
+        for key in a_:
+            assert torch.equal(a_[key], b_[key]), key
+
+
+@pytest.mark.parametrize("density", [0.0, 1e-3, 0.05, 0.3, 1.0])
+@pytest.mark.parametrize("shared_map", [True, False])
+def test_hot_pixel_queue_at_every_density(eng, density, shared_map):
+    """The queue-driven hot-pixel pass (scan -> one queued element per lane) against the oracle and against the workspace-free
+    pass, from an empty map to one where EVERY element is hot (the queue holds a quarter of the elements: 0.3 and 1.0 overflow
+    it and must fall back, bit-identically), one map shared by all frames and a different map per frame; 137 x 61 x 3 elements
+    are not a multiple of the 1024-element span a wave scans."""
+    n, h, w = 5, 137, 61
+    rng = np.random.default_rng(int(density * 1000) + 7 * shared_map)
+    frames, stds, t = orc.synthetic_stack(77, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    def one_map():
+        d = rng.integers(0, 10, size=(h, w, 3)).astype(np.uint8)
+        d[rng.random((h, w, 3)) < density] = 200
+        return d
+    maps = [one_map()] * n if shared_map else [one_map() for _ in range(n)]
+    dk = [dev(m) for m in maps]
+    if shared_map:
+        dk = [dk[0]] * n
+    ref = orc.merge(frames, t, icrf, diff, stds=stds, darks=[orc.unit_from_u8(m) for m in maps], dark_threshold=99.5 / 255, median_k=3)
+    fr, sd = [dev(f) for f in frames], [dev(s) for s in stds]
+    plan = eng.plan_merge(fr, t, icrf, diff, sd, darks=dk, dark_min=[100] * n, median_k=3)
+    assert "merge_scan_hot + merge_patch_hot" in plan.kernels
+    plan.launch()
+    close(host(plan.outputs["val"]), ref["val"], VAL_RTOL)
+    close(host(plan.outputs["std"]), ref["std"], STD_RTOL)
+    old = eng.plan_merge(fr, t, icrf, diff, sd, darks=dk, dark_min=[100] * n, median_k=3, hot_queue=False)
+    assert "merge_scan_hot" not in old.kernels and "merge_fixup_hot" in old.kernels
+    old.launch()
+    assert torch.equal(plan.outputs["val"], old.outputs["val"]) and torch.equal(plan.outputs["std"], old.outputs["std"])
+    # launching the same plan again reuses its workspace (the counters are reset on the stream)
+    plan.outputs["val"].zero_()
+    plan.launch()
+    assert torch.equal(plan.outputs["val"], old.outputs["val"])
+
+
+def test_hot_pixel_queue_smallest_workspace(eng):
+    """Any workspace from hm_merge_hot_workspace_bytes(1) = 20 bytes up is legal: a one-entry queue overflows on the second hot
+    element and the gated fallback pass produces the image."""
+    import ctypes as C
+    n, h, w = 3, 40, 33
+    frames, stds, t = orc.synthetic_stack(78, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    rng = np.random.default_rng(78)
+    d = (rng.random((h, w, 3)) < 0.02).astype(np.uint8) * 200
+    fr, sd, dk = [dev(f) for f in frames], [dev(s) for s in stds], dev(d)
+    plan = eng.plan_merge(fr, t, icrf, diff, sd, darks=[dk] * n, dark_min=[100] * n, median_k=3)
+    small = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    plan.args.hot_workspace, plan.args.hot_workspace_bytes = small.data_ptr(), 20
+    plan.launch()
+    torch.cuda.synchronize()
+    words = small.cpu().numpy().view(np.uint32)
+    assert words[0] >= 1 and words[1] == 1                 # something was queued, then the queue overflowed
+    old = eng.plan_merge(fr, t, icrf, diff, sd, darks=[dk] * n, dark_min=[100] * n, median_k=3, hot_queue=False)
+    old.launch()
+    assert torch.equal(plan.outputs["val"], old.outputs["val"]) and torch.equal(plan.outputs["std"], old.outputs["std"])
 
 
 @pytest.mark.parametrize("n", [7, 17, 20, 32])
@@ -681,7 +745,7 @@ def test_config3_full_size_with_corrections(eng):
     dmin = [eng.dark_min_dn(1.0, thr)] * n
     kw = dict(dark_min=dmin, median_k=3, ff_mean=ffm, ff_std_mean=ffs)
     base = eng.plan_merge(frames, t, icrf, diff, stds, darks=darks, flat=flat, flat_std=flat_std, **kw)
-    assert "merge_u8_fast_std" in base.kernels and "merge_fixup_hot" in base.kernels
+    assert "merge_u8_fast_std" in base.kernels and "merge_scan_hot + merge_patch_hot" in base.kernels
     base.launch()
     val, std = base.outputs["val"], base.outputs["std"]
     assert bool(torch.isfinite(val).all()) and bool(torch.isfinite(std).all())
@@ -730,7 +794,7 @@ def test_config4_row_tile_shape(eng, with_std):
     cutv = lambda x: None if x is None else x[3071 - lo:]                    # noqa: E731  (views: contiguous row slices, no copies)
     tile = eng.plan_merge([cutv(f) for f in frames], t, icrf, diff if with_std else None, None if stds is None else [cutv(s) for s in stds],
                           darks=[cutv(d) for d in darks], dark_min=dmin, median_k=3, height=Himg, row0=3072, rows=1024, buf_row0=3071)
-    assert ("merge_u8_fast_std<N=15" if with_std else "merge_u8_val3<N=15") in tile.kernels and "merge_fixup_hot" in tile.kernels
+    assert ("merge_u8_fast_std<N=15" if with_std else "merge_u8_val3<N=15") in tile.kernels and "merge_patch_hot" in tile.kernels
     tile.launch()
     assert torch.equal(tile.outputs["val"], big.outputs["val"][1024:])
     if with_std:

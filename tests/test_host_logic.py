@@ -31,9 +31,9 @@ def test_library_exports_every_declared_symbol():
 def test_merge_args_layout_matches_header():
     from camera_linearity_amd import _native as nat
     # offsets of include/hdrmerge.h's struct on LP64 (checked against a C compile in the build container)
-    assert C.sizeof(nat.MergeArgs) == 264
+    assert C.sizeof(nat.MergeArgs) == 280
     assert nat.MergeArgs.frames_u8.offset == 64 and nat.MergeArgs.ff_mean.offset == 176
-    assert nat.MergeArgs.out_sum_w.offset == 256
+    assert nat.MergeArgs.out_sum_w.offset == 256 and nat.MergeArgs.hot_workspace.offset == 264
 
 
 def test_argument_validation_without_device():
@@ -219,7 +219,7 @@ def test_oracle_is_test_infrastructure_only():
 
 
 # ---------------------------------------------------------------------------------------------- dispatch (no GPU needed)
-def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False, variant=0, align=0, darks=False):
+def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False, variant=0, align=0, darks=False, hot_ws=False):
     """hm_merge_describe runs hm_merge's own dispatch with launching switched off: pointers only need to look aligned."""
     import ctypes as C_
     from camera_linearity_amd import _native as nat
@@ -255,6 +255,8 @@ def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False
         a.dark_min_dn = C_.cast(dm, C_.POINTER(C_.c_int32))
         a.median_k = 3
         keep += [dk, dm]
+        if hot_ws:
+            a.hot_workspace, a.hot_workspace_bytes = base * 91, nat.lib.hm_merge_hot_workspace_bytes(H * W * C)
     buf = C_.create_string_buffer(512)
     rc = nat.lib.hm_merge_describe(C_.byref(a), buf, 512)
     return rc, buf.value.decode()
@@ -272,6 +274,11 @@ def test_merge_dispatch_table():
     assert _describe(7, H=5, W=64)[1] == "merge_u8_val3<N=7,U=4,PF=1,MAP=0> + merge_generic<f64in=0,std=0>"   # 960 = 1 unit of 512 + tail
     assert _describe(7, std=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0>"
     assert _describe(7, std=True, flat=True, darks=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=1,sum_w=0> + merge_fixup_hot<f64in=0,std=1>"
+    # with a queue workspace the hot-pixel pass is scan -> balanced patch (-> the old pass, gated on the queue's overflow flag)
+    assert _describe(7, std=True, darks=True, hot_ws=True)[1] == ("merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0> + merge_scan_hot + merge_patch_hot<f64in=0,std=1>"
+                                                                 "")
+    assert nat.lib.hm_merge_hot_workspace_bytes(4096 * 4096 * 3) == 16 + 4096 * 4096 * 3      # a quarter of the elements, 4 bytes each
+    assert nat.lib.hm_merge_hot_workspace_bytes(100) == 16 + 400 and nat.lib.hm_merge_hot_workspace_bytes(0) == 20
     assert _describe(7, sumw=True)[1] == "merge_u8_fast<N=7,U=2,flat=0,sum_w=1>"
     assert _describe(17)[1] == "merge_u8_loop<C=3,flat=0,sum_w=0>(N=17)"
     assert _describe(7, C=1)[1] == "merge_u8_loop<C=1,flat=0,sum_w=0>(N=7)"

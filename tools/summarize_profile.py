@@ -4,12 +4,15 @@ per-kernel time from --kernel-trace --stats, PMC counters per launch of the merg
 traffic corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and on gfx950
 reads exactly 1/2 of a wide coalesced streaming read's bytes -> doubled; WRITE_SIZE in KiB, exact).
 usage: summarize_profile.py <prof dir> <tag> [kernel substring] [algorithmic bytes] [workload] [commit]
-With a workload name it also records the measured HBM bytes per launch in profiles/r02_pmc_traffic.json (what bench.py
+With a workload name it also records the measured HBM bytes per launch in profiles/<round>_pmc_traffic.json (round = $HM_ROUND, default r03; what bench.py
 prints as roofline.traffic, with the commit the counters were collected on).
-DATA-DEPENDENT KERNELS: pass the dominant kernel's name substring; counters are averaged over its launches only."""
+DATA-DEPENDENT KERNELS: pass the dominant kernel's name substring; counters are averaged over its launches only.
+A workload that is several kernels per step (config 3: streaming merge + hot-pixel pass) passes "nameA+nameB": the step time is the
+sum of the kernels' average durations and the counters are summed over them (each averaged over its own launches)."""
 import csv
 import glob
 import json
+import os
 import statistics
 import sys
 
@@ -23,21 +26,31 @@ rows = list(csv.DictReader(open(ks[0])))
 out["kernel_stats"] = [{"name": r["Name"][:90], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                         "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])}
                        for r in rows[:6]]
-merge = next(r for r in out["kernel_stats"] if kname in r["name"])
+knames = kname.split("+")
+parts = [next(r for r in out["kernel_stats"] if kn in r["name"]) for kn in knames]
+merge = dict(parts[0])
+if len(parts) > 1:
+    merge["name"] = " + ".join(p_["name"] for p_ in parts)
+    for key in ("avg_us", "min_us", "max_us", "pct"):
+        merge[key] = sum(p_[key] for p_ in parts)
+    out["step_kernels"] = parts
 counters = {}
 for f in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
     per = {}
-    info = None
+    info = {}
     for r in csv.DictReader(open(f)):
-        if kname not in r["Kernel_Name"]:
+        kn = next((k_ for k_ in knames if k_ in r["Kernel_Name"]), None)
+        if kn is None:
             continue
-        info = info or r
-        per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in per.items():
-        counters[k] = statistics.mean(v)
-    if info:
-        out["launch"] = {k: info[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
-                                               "Workgroup_Size", "Grid_Size") if k in info}
+        info.setdefault(kn, r)
+        per.setdefault((kn, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    tot = {}
+    for (kn, k), v in per.items():
+        tot[k] = tot.get(k, 0.0) + statistics.mean(v)
+    counters.update(tot)
+    for kn, r in info.items():
+        out.setdefault("launch", {})[kn] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                                                             "Workgroup_Size", "Grid_Size") if k in r}
 out["counters_per_launch"] = counters
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     rd = counters["FETCH_SIZE"] * 1024 * 2          # gfx950 correction: counter reads 1/2 of wide streaming reads
@@ -49,7 +62,8 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
 c = counters
 d = {}
 if "SQ_WAVE_CYCLES" in c:
-    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS"):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS",
+              "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_INST_CYCLES_VMEM", "SQ_ACTIVE_INST_FLAT"):
         if k in c:
             d[k + "/WAVE_CYCLES"] = c[k] / c["SQ_WAVE_CYCLES"]
 if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
@@ -63,7 +77,8 @@ out["merge_kernel"] = merge
 out["roofline"] = {"achieved_GBps": alg / merge["avg_us"] / 1e3, "frac_of_8TBps": alg / merge["avg_us"] / 1e3 / 8000}
 json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)
 with open(f"profiles/{tag}_rocprof_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary ({tag})\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline` "
+    f.write(f"# rocprofv3 summary ({tag})\n\nCommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline"
+            + (f" --workload {sys.argv[5]}" if len(sys.argv) > 5 and sys.argv[5] != "cfg2" else "") + "` "
             "and one `--pmc` pass per counter group (tools/profile.sh).\n\n## Kernel stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for r in out["kernel_stats"]:
         f.write(f"| `{r['name']}` | {r['calls']} | {r['avg_us']:.1f} | {r['min_us']:.1f} | {r['max_us']:.1f} | {r['pct']:.1f} |\n")
@@ -79,7 +94,7 @@ with open(f"profiles/{tag}_rocprof_summary.md", "w") as f:
         f.write("\n## Derived\n\n" + "\n".join(f"- {k}: {v:.4g}" for k, v in d.items()) + "\n")
 if len(sys.argv) > 5 and "traffic" in out:
     import pathlib
-    tp = pathlib.Path("profiles/r02_pmc_traffic.json")
+    tp = pathlib.Path(f"profiles/{os.environ.get('HM_ROUND', 'r03')}_pmc_traffic.json")
     rec = json.load(open(tp)) if tp.exists() else {}
     rec[sys.argv[5]] = {"hbm_bytes_per_launch": out["traffic"]["hbm_bytes_per_launch"], "ratio_to_algorithmic": out["traffic"]["ratio_to_algorithmic"],
                         "kernel": merge["name"], "commit": sys.argv[6] if len(sys.argv) > 6 else "?", "source": f"profiles/{tag}_rocprof_summary.json"}
