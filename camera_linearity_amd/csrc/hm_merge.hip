@@ -412,8 +412,10 @@ __global__ __launch_bounds__(256) void merge_fixup_hot(const MergeK a) {
     }
 }
 
-// merge_scan_hot: the scan alone. A wave scans kScanRound spans of 1024 elements per round (16 bytes per lane, map and span: up to
-// 8 x #maps loads in flight per lane), the workgroup's 16 waves add up their counts through LDS and ONE atomic add per workgroup
+// merge_scan_hot: the scan alone. A wave scans kScanRound consecutive spans of 1024 elements per round (16 bytes per lane, map and
+// span, the round's loads of a map issued together), a workgroup's 16 waves 64 consecutive spans = 65 536 elements (a few image
+// rows: what lands next to each other in the queue shares its neighbour rows, which the patch kernel then finds in the cache).
+// The waves add up their counts through LDS and ONE atomic add per workgroup
 // and round reserves its piece of the queue (an atomic per wave and span serialised on the counter: 49 000 returning atomics on
 // one address took 365 us at a density of 1e-3, profiles/r03c_hot_trace.txt). Every wave runs the same number of rounds (barriers).
 // The order of the pieces in the queue depends on the order of the atomics; the patched image does not (every queued element is
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uin
             bool valid[kScanRound];
 #pragma unroll
             for (int k = 0; k < kScanRound; ++k) {
-                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                const int64_t chunk = (((r * n_waves + wave_global) * kScanRound) + k) * 64 + lane;
                 valid[k] = chunk < n_full;
                 off[k] = a.in_off + a.elem0 + (valid[k] ? chunk : 0) * 16;
                 hb[k] = 0;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uin
             }
 #pragma unroll
             for (int k = 0; k < kScanRound; ++k) {
-                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                const int64_t chunk = (((r * n_waves + wave_global) * kScanRound) + k) * 64 + lane;
                 if (!valid[k]) hb[k] = 0;
                 if (chunk == n_full && chunk < n_chunks)                    // the tile's last, partial chunk (one lane of one wave)
                     hb[k] = scan_chunk_hotbits(a, a.elem0 + chunk * 16, static_cast<int>(a.n_elems - chunk * 16));
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uin
         } else {
 #pragma unroll
             for (int k = 0; k < kScanRound; ++k) {
-                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                const int64_t chunk = (((r * n_waves + wave_global) * kScanRound) + k) * 64 + lane;
                 hb[k] = 0;
                 if (chunk < n_chunks) {
                     const int64_t e0 = a.elem0 + chunk * 16;
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uin
 #pragma unroll
             for (int k = 0; k < kScanRound; ++k) {
                 uint32_t bits = hb[k];
-                const int64_t chunk = ((r * kScanRound + k) * n_waves + wave_global) * 64 + lane;
+                const int64_t chunk = (((r * n_waves + wave_global) * kScanRound) + k) * 64 + lane;
                 const uint32_t first = static_cast<uint32_t>(a.elem0 + chunk * 16);   // < 2^32 (host check)
                 while (bits) {
                     const int b = __ffs(static_cast<int>(bits)) - 1;
@@ -697,15 +699,23 @@ __global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uin
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t B = (count + n_waves - 1u) / n_waves;
     B = B > 64u ? 64u : B;
-    if (overflow == 0u && (count == 0u || blockIdx.x * 4u * B >= count)) return;
+    if (overflow == 0u && count == 0u) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t wave = threadIdx.x >> 6;
+    // A workgroup owns a CONTIGUOUS piece of the queue (4 B entries per iteration, `iters` iterations), and workgroups that run on the
+    // same XCD (blockIdx % 8: round-robin dispatch) own neighbouring pieces - entries that are neighbours in the queue are neighbours in
+    // the image (merge_scan_hot), so the rows they share are fetched into ONE L2 once.
+    const uint32_t iters = B ? (count + n_waves * B - 1u) / (n_waves * B) : 0u;
+    const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+    const uint32_t logical = gridDim.x % 8u == 0u ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+    const uint64_t wg_first = static_cast<uint64_t>(logical) * 4u * B * iters;
+    if (overflow == 0u && wg_first >= count) return;
     // the first entry and its dark bytes are fetched while the workgroup builds its tables (a short queue is one entry per lane:
     // its latency is the kernel's duration)
     int64_t e_first = 0;
     uint32_t hot_first = 0;
-    if (overflow == 0u && lane < B && static_cast<uint64_t>(wave_id) * B + lane < count) {
-        e_first = static_cast<int64_t>(ws[kHotQueueHeader + static_cast<uint64_t>(wave_id) * B + lane]);
+    if (overflow == 0u && lane < B && wg_first + wave * B + lane < count) {
+        e_first = static_cast<int64_t>(ws[kHotQueueHeader + wg_first + wave * B + lane]);
         hot_first = lane_hotmask(a, a.in_off + e_first);
     }
     fill_plain_tables<F64IN, STD>(a, t_w, t_dw, t_g, t_d);
@@ -719,19 +729,17 @@ __global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uin
         }
         return;
     }
-    bool first = true;
-    for (uint64_t base = static_cast<uint64_t>(wave_id) * B; base < count; base += static_cast<uint64_t>(n_waves) * B) {
-        const uint64_t q = base + lane;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t q = wg_first + (static_cast<uint64_t>(it) * 4u + wave) * B + lane;
         if (lane < B && q < count) {
             int64_t e = e_first;
             uint32_t hotmask = hot_first;
-            if (!first) {
+            if (it != 0u) {
                 e = static_cast<int64_t>(ws[kHotQueueHeader + q]);
                 hotmask = lane_hotmask(a, a.in_off + e);
             }
             patch_element<F64IN, STD>(a, t_w, t_dw, t_g, t_d, keep_lds, e, hotmask);
         }
-        first = false;
     }
 }
 
