@@ -1,5 +1,6 @@
 // hm_api.hip - version / error strings / device query / host-side weight table of libhdrmerge.
 #include "hm_common.h"
+#include "hdrmerge_debug.h"
 #include <cmath>
 #include <cstring>
 

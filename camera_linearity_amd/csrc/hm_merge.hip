@@ -1175,11 +1175,12 @@ __device__ __forceinline__ double merge_div(double a, double b) {
     if constexpr (FASTDIV) return div_inrange(a, b);
     else return a / b;
 }
-// table entry check behind div_inrange: w in [2^-64, 2^64]; w*g either +0 (bit pattern) or |w*g| in [2^-300, 2^300]
+// table entry check behind div_inrange: w in [2^-64, 2^64]; w*g either +0 (bit pattern) or in [2^-300, 2^300] - POSITIVE: with
+// entries of both signs the fma chain could cancel far below any single term (down to ~2^-706 for 16 frames), outside the range the
+// argument above covers. Non-negative terms only grow the sum: acc is +0 or in [2^-600, 2^605] (times 1/t in [2^-300, 2^300], 16 terms).
 __device__ __forceinline__ bool entry_inrange(double w, double wg) {
     const bool w_ok = w >= 0x1p-64 && w <= 0x1p64;
-    const double m = fabs(wg);
-    const bool wg_ok = __double_as_longlong(wg) == 0 || (m >= 0x1p-300 && m <= 0x1p300);
+    const bool wg_ok = __double_as_longlong(wg) == 0 || (wg >= 0x1p-300 && wg <= 0x1p300);
     return w_ok && wg_ok;
 }
 
@@ -1332,7 +1333,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
 }
 
 #if HM_TUNE_NF != 0
-#include "hm_merge_priv.inc"     // merge_u8_priv: the conflict-free-LDS experiment (tuning builds only)
+#include "../../tools/hm_merge_priv.inc"     // merge_u8_priv: the conflict-free-LDS experiment (tuning builds only, lives with the other experiments)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1858,7 +1859,7 @@ static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
     return c.u >= 1 && c.u <= 8 && c.pf <= 1 && c.map <= 2;
 }
 #if HM_TUNE_NF != 0
-#include "hm_merge_priv_launch.inc"
+#include "../../tools/hm_merge_priv_launch.inc"
 #else
 static bool priv_variant(int, int, int&) { return false; }       // merge_u8_priv exists in tuning builds only
 #endif

@@ -409,7 +409,8 @@ extern "C" int hm_pow_scalar(const double* x, const double* s, double exponent, 
     if (!aligned(x, 8) || !aligned(out_val, 8)) return HM_EALIGN;
     hipStream_t st = as_stream(stream);
     const double p = exponent;
-    const int ip = (p == static_cast<double>(static_cast<int>(p)) && p >= -8.0 && p <= 8.0) ? static_cast<int>(p) : 0;
+    const bool small = p >= -8.0 && p <= 8.0;                       // range first: double -> int is undefined outside int's range and for NaN
+    const int ip = (small && p == static_cast<double>(static_cast<int>(p))) ? static_cast<int>(p) : 0;
     // whole 512-element chunks of 16-byte aligned buffers in the burst access shape (the cheap exponents: a general pow() is compute-bound)
     const bool al16 = aligned(x, 16) && aligned(out_val, 16) && (!s || (aligned(s, 16) && aligned(out_std, 16)));
     const int64_t n_chunks = n / kBurstChunk;

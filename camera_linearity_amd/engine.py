@@ -511,6 +511,9 @@ def elementwise_unary(op: int, x: torch.Tensor, s):
 # ---------------------------------------------------------------------------------------------
 # linearity statistics
 # ---------------------------------------------------------------------------------------------
+HM_TAKE_MAX = 16          # include/hdrmerge.h
+
+
 def take_axis(x: torch.Tensor, s: Optional[torch.Tensor], indices: Sequence[int], axis: Optional[int]):
     """modules/measurand.py:352-373 (`lib.take(val, dims, axis)`): axis=None indexes the flattened array."""
     _require_cuda(x, "val")
@@ -531,10 +534,28 @@ def take_axis(x: torch.Tensor, s: Optional[torch.Tensor], indices: Sequence[int]
         raise IndexError(f"index out of bounds for axis of size {axis_len}")
     out = torch.empty(out_shape, dtype=_F64, device=x.device)
     out_s = None if s is None else torch.empty(out_shape, dtype=_F64, device=x.device)
-    arr = (C.c_int64 * len(idx))(*idx)
     with torch.cuda.device(x.device):
-        nat.check(nat.lib.hm_take_axis(x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_s), outer, axis_len, inner,
-                                       arr, len(idx), _stream(x.device)), "hm_take_axis")
+        if len(idx) <= HM_TAKE_MAX:
+            arr = (C.c_int64 * len(idx))(*idx)
+            nat.check(nat.lib.hm_take_axis(x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_s), outer, axis_len, inner,
+                                           arr, len(idx), _stream(x.device)), "hm_take_axis")
+        else:
+            # np.take has no limit on the number of indices; hm_take_axis takes HM_TAKE_MAX per launch: one launch per chunk into its
+            # slice of the dense (outer, n, inner) output (a strided device copy when outer > 1)
+            ov = out.view(outer, len(idx), inner)
+            osv = None if out_s is None else out_s.view(outer, len(idx), inner)
+            for k0 in range(0, len(idx), HM_TAKE_MAX):
+                part = idx[k0:k0 + HM_TAKE_MAX]
+                arr = (C.c_int64 * len(part))(*part)
+                direct = outer == 1
+                tv = ov[:, k0:k0 + len(part)] if direct else torch.empty((outer, len(part), inner), dtype=_F64, device=x.device)
+                ts = None if s is None else (osv[:, k0:k0 + len(part)] if direct else torch.empty_like(tv))
+                nat.check(nat.lib.hm_take_axis(x.data_ptr(), nat.ptr(s), tv.data_ptr(), nat.ptr(ts), outer, axis_len, inner,
+                                               arr, len(part), _stream(x.device)), "hm_take_axis")
+                if not direct:
+                    ov[:, k0:k0 + len(part)].copy_(tv)
+                    if ts is not None:
+                        osv[:, k0:k0 + len(part)].copy_(ts)
     return out, out_s
 
 

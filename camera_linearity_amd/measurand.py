@@ -325,6 +325,8 @@ class HipMeasurand(AbstractMeasurand):
     # libhdrmerge or an explicit error - there are no torch arithmetic fallbacks (tests/test_gpu_api.py asserts which symbol ran)
     def extract(self, dims=None, axis: Optional[int] = None):
         """modules/measurand.py:352-373: lib.take(val, dims, axis); axis=None indexes the flattened array (hm_take_axis)."""
+        if dims is None:
+            raise TypeError("extract() needs the indices to take (dims); the reference's lib.take(val, None, axis) raises too")
         target = [dims] if type(dims) is int else list(dims)
         value, std = _engine().take_axis(self._f64(), self.std, target, axis)
         return self.__class__(value, std)

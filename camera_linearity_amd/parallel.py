@@ -164,9 +164,11 @@ class RowTileSet:
         side.synchronize()
         return out
 
-    def assemble(self, group=None, dst: int = 0):
+    def assemble(self, group=None, dst: int = 0, copy: bool = False):
         """(val, std) of the whole image as host tensors on `dst`, (None, None) elsewhere. The destination rank's own tiles go from the
-        device straight into their rows of the (pinned) image; the other ranks' tiles arrive over the CPU group into theirs."""
+        device straight into their rows of the (pinned) image; the other ranks' tiles arrive over the CPU group into theirs.
+        The returned tensors ARE this object's pinned image buffers: the next assemble() (the next stack of a loop) overwrites them.
+        copy=True returns tensors of the caller's own instead (one more host copy of the image)."""
         image = None
         if self.rank == dst and self.mine:
             o = self.plans[self.mine[0]].outputs
@@ -178,17 +180,23 @@ class RowTileSet:
                 self._image_key = key
             image = self._image
         local = self.download(into=image)
-        return gather_tiles(local, self.bounds, group=group, dst=dst, world_size=self.world, rank=self.rank, image=image)
+        val, std = gather_tiles(local, self.bounds, group=group, dst=dst, world_size=self.world, rank=self.rank, image=image)
+        if copy and val is not None:
+            val, std = val.clone(), (None if std is None else std.clone())
+        return val, std
 
 
 def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst: int = 0, world_size: int = 1, rank: int = 0, image=None):
     """Assemble {tile index: (val, std | None)} dictionaries of all ranks into one image on `dst`. With one rank this is a
     concatenation into a preallocated buffer; with several, every tile travels as ONE tensor send / receive over the CPU
     (gloo) group straight into its rows of the destination image. `image` = (val, std | None) preallocated on `dst` whose rows already
-    hold dst's own tiles (RowTileSet.assemble): those are not copied again."""
+    hold dst's own tiles (RowTileSet.assemble): those are not copied again - and `image` itself is what is returned on dst (aliased,
+    not a copy)."""
     some = next(iter(local.values())) if local else None
     with_std = some is not None and some[1] is not None
     if world_size == 1:
+        if some is None:
+            raise ValueError("gather_tiles: this (only) rank holds no tiles to assemble")
         shape_tail = tuple(some[0].shape[1:])
         if image is not None:
             return image[0], (image[1] if with_std else None)

@@ -50,16 +50,7 @@ enum {
 int hm_version(void);                 /* HM_ABI_VERSION of the loaded library          */
 const char* hm_strerror(int code);    /* static string, never NULL                     */
 int hm_device_info(int* n_devices, int* cu_count, int* lds_bytes, char* arch, int arch_len);
-/* Diagnostic: one wave samples the shader-cycle counter and the 100 MHz real-time counter over `spins` sleep periods on `stream` (launch it on a
- * side stream while the kernels of interest run): out_device[0] = shader cycles, out_device[1] = 100 MHz ticks -> clock [GHz] = [0] / [1] / 10. */
-int hm_debug_clock_probe(unsigned long long* out_device, int spins, void* stream);
-/* Debug: dst[0 .. bytes) = src[0 .. bytes) with 16-byte nontemporal loads and stores (16-byte aligned, bytes a multiple of 16): the
- * copy bandwidth of the box, against which bench.py holds the merge's read / write mix (roofline.copy_GBps). No reference counterpart. */
-int hm_debug_copy_probe(const void* src, void* dst, unsigned long long bytes, void* stream);
-/* Debug: `blocks` x 256 threads each read `passes` dwords, every one from a different `stride_bytes`-sized page of buf[0 .. bytes): the
- * launch time reflects the address-translation cost of the buffer's physical backing (tools/tlb_probe.py). No reference counterpart. */
-int hm_debug_stride_probe(const void* buf, unsigned long long bytes, unsigned long long stride_bytes, int passes, int blocks,
-                          unsigned int* sink_device, void* stream);
+/* (diagnostic probes - clock, copy rate, address translation - are declared in hdrmerge_debug.h: they replace nothing in the reference) */
 
 /* ------------------------------------------------------------------------------------------
  * Row 3 - AbstractMeasurand.apply_gaussian_weight (modules/measurand.py:606-618)

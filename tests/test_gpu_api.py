@@ -334,6 +334,15 @@ def test_measurand_methods_run_their_hip_kernels(M):
     np.testing.assert_array_equal(ex.val.cpu().numpy(), np.take(a, [1], axis=0))
     with pytest.raises(IndexError):
         A.extract([3], axis=-1)
+    with pytest.raises(TypeError):
+        A.extract(None, axis=0)
+    # more indices than one hm_take_axis launch takes (HM_TAKE_MAX = 16): chunked, np.take has no limit
+    many = list(rng.integers(-7, 7, 41))
+    ex = ran("hm_take_axis", lambda: A.extract(many, axis=1))                         # outer = 6 > 1: chunks land through strided copies
+    np.testing.assert_array_equal(ex.val.cpu().numpy(), np.take(a, many, axis=1))
+    np.testing.assert_array_equal(ex.std.cpu().numpy(), np.take(0.1 * a, many, axis=1))
+    flat_idx = list(rng.integers(-126, 126, 50))
+    np.testing.assert_array_equal(A.extract(flat_idx).val.cpu().numpy(), np.take(a, flat_idx))
     ran("hm_apply_thresholds", lambda: M(a.copy()).apply_thresholds([0.3, None, 0.2], [0.9, 0.8, None]))
     wide = rng.random((5, 9))                                                         # 9 channels: the wide kernel, still HIP
     W9 = M(wide.copy(), 0.1 * wide)

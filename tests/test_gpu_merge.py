@@ -882,3 +882,122 @@ def test_correction_kernels_on_a_large_frame(eng):
     om, om2, oc = orc.welford_state(frames)
     assert c == oc == 5
     assert np.array_equal(host(mean), om) and np.array_equal(host(m2), om2)
+
+
+def test_headline_kernel_steady_state(eng):
+    """The bench kernel itself at the bench size on NON-constant data: 7 x 4096 x 4096 x 3 val-only goes to merge_u8_val3<N=7,U=4,PF=1>
+    and a wave needs more than 6.3 M elements (3072 workgroups x 4 waves x 512 elements) before it iterates and enters the RA / RB
+    register ping-pong - smaller tests only ever run the prologue and the last-unit path. Held to: the generic kernel bit for bit
+    (every element), two row tiles bit for bit (different unit -> wave assignment), a 64-row band of the oracle at three places."""
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf
+    n, H, W = 7, 4096, 4096
+    frames, _, t = synthetic_stack_device(23, n, H, W, device="cuda")
+    icrf, _ = synthetic_icrf()
+    plan = eng.plan_merge(frames, t, icrf)
+    assert plan.kernels == "merge_u8_val3<N=7,U=4,PF=1,MAP=0>"
+    plan.launch()
+    val = plan.outputs["val"]
+    gen = eng.plan_merge(frames, t, icrf, variant=-1)
+    assert gen.kernels == "merge_generic<f64in=0,std=0>"
+    gen.launch()
+    assert torch.equal(gen.outputs["val"], val)
+    del gen
+    cut = 2311                                     # 2311 * 12288 elements: not a multiple of the 512-element unit -> generic tail in the top tile
+    top = eng.merge([f[:cut] for f in frames], t, icrf, height=H, row0=0, rows=cut, buf_row0=0)
+    bot = eng.merge([f[cut:] for f in frames], t, icrf, height=H, row0=cut, rows=H - cut, buf_row0=cut)
+    assert torch.equal(top["val"], val[:cut]) and torch.equal(bot["val"], val[cut:])
+    del top, bot
+    for r0 in (0, 2000, H - 64):
+        ref = orc.merge([f[r0:r0 + 64].cpu().numpy() for f in frames], t, icrf)
+        close(host(val[r0:r0 + 64]), ref["val"], VAL_RTOL)
+    # uniform-random DNs (every LDS gather conflicts): same checks against the generic kernel
+    frames, _, t = synthetic_stack_device(24, n, H, W, device="cuda", uniform_dn=True)
+    a_ = eng.merge(frames, t, icrf)["val"]
+    b_ = eng.merge(frames, t, icrf, variant=-1)["val"]
+    assert torch.equal(a_, b_)
+
+
+def test_config5_shape_eight_resident_stacks(eng):
+    """BASELINE configs[4] on one GPU's share: 8 distinct resident 7 x 4096 x 4096 x 3 stacks merged back to back on one stream
+    (what bench.py --workload cfg5 times), each output band-checked against the oracle and all eight different."""
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf
+    n, H, W = 7, 4096, 4096
+    icrf, _ = synthetic_icrf()
+    plans, stacks = [], []
+    for k in range(8):
+        frames, _, t = synthetic_stack_device(300 + k, n, H, W, device="cuda")
+        plans.append(eng.plan_merge(frames, t, icrf))
+        stacks.append((frames, t))
+    for _ in range(2):
+        for p in plans:
+            p.launch()
+    torch.cuda.synchronize()
+    sums = set()
+    for k, (p, (frames, t)) in enumerate(zip(plans, stacks)):
+        assert p.kernels == "merge_u8_val3<N=7,U=4,PF=1,MAP=0>"
+        r0 = 37 * k
+        ref = orc.merge([f[r0:r0 + 32].cpu().numpy() for f in frames], t, icrf)
+        close(host(p.outputs["val"][r0:r0 + 32]), ref["val"], VAL_RTOL)
+        sums.add(int(p.outputs["val"].view(torch.int64).sum().item()))
+    assert len(sums) == 8
+
+
+def test_fast_division_fallback_branches(eng):
+    """merge_u8_val3 divides with an unscaled reciprocal-Newton-Markstein sequence only while its table check proves every operand in
+    range, and takes the IEEE division otherwise (a wave-uniform branch no other test reaches: their tables are positive and tame).
+    Tables with negative, -0.0, denormal and huge entries, and exposures of 1e-120 / 1e120, must give the generic kernel's bits."""
+    rng = np.random.default_rng(5)
+    n, h, w = 7, 96, 130                                           # 37 440 elements: 73 units of 512 + a tail
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+    fr = [dev(f) for f in frames]
+    t_ok = list(1e-3 * 2.0 ** np.arange(n))
+    base = np.linspace(0, 1, 256)[:, None] ** np.array([2.2, 2.0, 1.8])[None, :]
+    cases = []
+    neg = base.copy(); neg[5:40, 0] *= -1.0; neg[0, :] = -0.0                      # negative and -0.0 entries
+    cases.append(("negative / -0.0 ICRF", neg, t_ok))
+    den = base.copy(); den[1:30, 1] = 1e-310; den[200:, 2] = 1e-305                  # denormal entries: w * g leaves [2^-300, 2^300]
+    cases.append(("denormal ICRF", den, t_ok))
+    big = base.copy(); big[100:130, :] = 1e200
+    cases.append(("huge ICRF", big, t_ok))
+    cases.append(("tiny exposures", base, [1e-120 * 2.0 ** i for i in range(n)]))    # 1 / t above 2^300: the host-side check
+    cases.append(("huge exposures", base, [1e120 * 2.0 ** i for i in range(n)]))
+    cases.append(("in range (fast path)", base, t_ok))
+    with np.errstate(all="ignore"):
+        for name, icrf, t in cases:
+            plan = eng.plan_merge(fr, t, icrf)
+            assert plan.kernels.startswith("merge_u8_val3<N=7,U=4,PF=1,MAP=0>"), name
+            plan.launch()
+            gen = eng.merge(fr, t, icrf, variant=-1)["val"]
+            a_, b_ = plan.outputs["val"], gen
+            assert torch.equal(a_.view(torch.int64), b_.view(torch.int64)), name        # bit patterns, NaN / inf / -0 included
+            ref = orc.merge(frames, t, icrf)["val"]
+            fin = np.isfinite(ref) & (np.abs(ref) > 1e-290)
+            np.testing.assert_allclose(host(a_)[fin], ref[fin], rtol=1e-12, err_msg=name)
+
+
+def test_row_tile_set_single_gpu_assembly(eng):
+    """RowTileSet with world_size = 1 and 8 tiles through launch() and assemble(): the side-stream D2H copies into the pinned image
+    reproduce a whole-image merge bit for bit (val and std, hot-pixel halo rows included); assemble() hands out its own buffers
+    (documented) and copy=True the caller's."""
+    from camera_linearity_amd import parallel
+    n, H, W, k = 5, 203, 64, 3                                     # 203 rows / 8 tiles: ragged tile heights
+    frames, stds, t = orc.synthetic_stack(91, n, H, W, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    rng = np.random.default_rng(91)
+    dark = (rng.random((H, W, 3)) < 0.01).astype(np.uint8) * 200
+    fr, sd, dk = [dev(f) for f in frames], [dev(s) for s in stds], dev(dark)
+    whole = eng.merge(fr, t, icrf, diff, sd, darks=[dk] * n, dark_min=[100] * n, median_k=k)
+    tiles = parallel.RowTileSet(H, 8, rank=0, world_size=1, median_k=k)
+    for tile in tiles.mine:
+        b0, b1 = tiles.input_rows(tile)
+        tiles.add_tile(tile, [f[b0:b1] for f in fr], t, icrf, diff, [s[b0:b1] for s in sd], darks=[dk[b0:b1]] * n, dark_min=[100] * n, median_k=k)
+    assert tiles.mine == list(range(8))
+    tiles.launch()
+    val, std = tiles.assemble()
+    assert val.is_pinned() and torch.equal(val, whole["val"].cpu()) and torch.equal(std, whole["std"].cpu())
+    val2, std2 = tiles.assemble()
+    assert val2.data_ptr() == val.data_ptr()                       # the same pinned buffers, reused
+    val3, _ = tiles.assemble(copy=True)
+    assert val3.data_ptr() != val.data_ptr() and torch.equal(val3, val)
+    with pytest.raises(ValueError):
+        parallel.gather_tiles({}, tiles.bounds, world_size=1)
