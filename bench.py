@@ -15,7 +15,7 @@ measured with HIP events on the launch stream inside the timed region; the cpu_b
 (a port of the reference's merge arithmetic) on a bounded row band of the same stack on the host, rank 0, N = 1 only,
 and checks the GPU output of the timed configuration against it.
 Other workloads (--workload): cfg3* = configs[2] and its parts, cfg4 / cfg4std = configs[3] (ONE 15 x 8192 x 8192 x 3 image
-in 8 row tiles dealt to the ranks, host-side assembly), cfg5 = configs[4], cfg2rand, cfg2smooth, cfg2f64 / cfg3f64std, welford, energy.
+in 8 row tiles dealt to the ranks, host-side assembly), cfg5 = configs[4], cfg2rand, cfg2smooth, cfg2f64 / cfg3f64std, welford, energy, linearity / linearitystd.
 """
 import argparse
 import json
@@ -374,12 +374,138 @@ def producer_workload(a, dev, rank=0, world=1, dist=None):
     print(json.dumps(line), flush=True)
 
 
+VALU_PEAK_GINSTR = 614.4        # FP64 vector issue rate of the part in 64-lane wave-instructions: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
+                                # (= 78.6 TFLOP/s of FP64 FMA, half of the guide's 157.3 TFLOP/s FP32 vector peak)
+
+
+def measured_valu(workload):
+    """VALU wave-instructions per launch of the all-pairs statistics kernel, from this round's PMC pass (profiles/r03_linearity_valu.json,
+    written by tools/summarize_profile.py with the commit it was collected on); None without such a record."""
+    tp = ROOT / "profiles" / "r03_linearity_valu.json"
+    try:
+        return json.load(open(tp)).get(workload)
+    except Exception:
+        return None
+
+
+def linearity_workload(a, dev, rank=0, world=1, dist=None):
+    """SURVEY.md 8(f)-1 as a bench workload: ExposureSeries.process_linearity (modules/exposure_series.py:421-446) on a device-resident
+    linearized series - 7 float64 frames of 4096 x 4096 x 3 (`linearitystd`: + 7 float64 std frames), the 15 exposure pairs with ratio
+    >= 0.1. A step = ONE hm_pairs_statistics launch: apply_thresholds on every frame in place (fused into the loads), absolute and
+    relative difference of every pair, (weighted) NaN-ignoring mean / std / error per channel - what process_linearity runs per call.
+    Two rooflines: HBM (every frame byte read once) and FP64 VALU (the kernel's binding resource). CPU leg = the NumPy oracle
+    (apply_thresholds + compute_difference + dimension_statistics per pair) on a row band; the GPU statistics of the same band are
+    checked against it. At N > 1 every rank runs its own series (replicas only: there is no exchange step)."""
+    from camera_linearity_amd import engine
+    from camera_linearity_amd.exposure_series import map_linearity_limits
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf
+    n, H, W = 7, 4096, 4096
+    use_std = a.workload == "linearitystd"
+    icrf, diff = synthetic_icrf()
+    frames, stds, t = synthetic_stack_device(7 + rank, n, H, W, device=dev, with_std=use_std)
+    lo, hi = map_linearity_limits(5, 5, icrf)
+    pairs = [(i, j, float(t[i] / t[j])) for i in range(n) for j in range(n) if i < j and t[i] / t[j] >= 0.1]   # exposure_series.py:283-304
+    rows_cpu = a.cpu_rows if a.cpu_rows > 0 else 192
+
+    def linearized(sl):
+        vals, sds = [], []
+        for f, sd in zip(frames, stds if use_std else [None] * n):
+            v, s_ = engine.linearize(f[sl], None if sd is None else sd[sl], icrf, diff if use_std else None)
+            vals.append(v)
+            sds.append(s_)
+        return vals, (sds if use_std else None)
+    # the band the CPU leg compares, linearized BEFORE anything is thresholded in place
+    cpu = None
+    band_stats = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        bv, bs = linearized(slice(0, rows_cpu))
+        band_host = ([v.cpu().numpy() for v in bv], None if bs is None else [x.cpu().numpy() for x in bs])
+        band_stats = engine.pairs_statistics(bv, bs, pairs, to_host=True, thresholds=(lo, hi))
+        del bv, bs
+    vals, sds = linearized(slice(None))
+    del frames, stds
+    launch = lambda: engine.pairs_statistics(vals, sds, pairs, thresholds=(lo, hi))      # noqa: E731
+    launch()                                            # the first call thresholds the frames (writes NaNs back); later calls find them thresholded
+    torch.cuda.synchronize()
+    E = H * W * 3
+    alg = n * 8 * (2 if use_std else 1) * E             # every frame (and std) byte once
+    steps, warmup = min(a.steps, 100), min(a.warmup, 10)
+    t_end = time.perf_counter() + a.prewarm_s
+    while time.perf_counter() < t_end:
+        launch()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        launch()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        launch()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    avg_us = ev0.elapsed_time(ev1) * 1e3 / steps
+    elapsed, ranks = rank_report(dist, a, dev, elapsed, avg_us)
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    if band_stats is not None:
+        from oracle import hdr_oracle as orc
+        hv, hs = band_host
+        c0 = time.perf_counter()
+        th = [orc.apply_thresholds(v, None if hs is None else hs[i], lo, hi) for i, v in enumerate(hv)]
+        worst = 0.0
+        with np.errstate(all="ignore"):
+            for k, (i, j, m) in enumerate(pairs):
+                d = orc.compute_difference(th[i][0], th[i][1], th[j][0], th[j][1], m)
+                for kind, (dv, ds) in enumerate(((d[0], d[1]), (d[2], d[3]))):
+                    st = orc.dimension_statistics(dv, ds, axis=(0, 1))
+                    got = band_stats[k][kind]
+                    for key in ("mean", "std") + (("error",) if use_std else ()):
+                        want = np.asarray(st[key], dtype=np.float64)
+                        g_ = np.asarray(got[key], dtype=np.float64)
+                        ok = np.isfinite(want)
+                        if ok.any():
+                            worst = max(worst, float(np.max(np.abs(g_[ok] - want[ok]) / np.maximum(np.abs(want[ok]), 1e-300))))
+        dt = time.perf_counter() - c0
+        cpu = {"value": round(len(pairs) * rows_cpu * W / dt / 1e6, 4), "unit": "Mpix-pairs/s", "cores": 1, "kind": "port",
+               "sample": f"rows 0..{rows_cpu - 1} of the series ({n}x{rows_cpu}x{W}x3 float64" + (" + std" if use_std else "") + f", {len(pairs)} pairs, {dt:.1f} s): "
+                         "apply_thresholds + compute_difference + dimension_statistics per pair, NumPy oracle, 1 thread of " + f"{os.cpu_count()} host cores",
+               "gpu_vs_oracle_max_rel_err": worst, "parity_ok": bool(worst <= 1e-10)}
+    valu = measured_valu(a.workload)
+    valu_block = None
+    if valu:
+        ginstr = valu["valu_wave_instructions_per_launch"] / avg_us / 1e3
+        valu_block = {"bound": "fp64-valu", "achieved": round(ginstr, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
+                      "instructions_per_element_pair": round(valu["valu_wave_instructions_per_launch"] * 64 / (len(pairs) * E), 1),
+                      "source": f"profiles/r03_linearity_valu.json ({valu.get('kernel', '?')} @ {valu.get('commit', '?')})"}
+    line = {"metric": "linearity-compared Mpix-pairs/s (process_linearity: 15 exposure pairs of 7 frames of 4096x4096x3)", "value": round(world * steps * len(pairs) * H * W / elapsed / 1e6, 1),
+            "unit": "Mpix-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n} linearized float64 frames of {H}x{W}x3" + (" + float64 std" if use_std else "") + f" per GPU, {len(pairs)} exposure pairs, thresholds fused, "
+                                   + ("weighted " if use_std else "") + "statistics of the absolute and relative differences per channel", "name": a.workload, "frames": n, "pairs": len(pairs),
+                       "height": H, "width": W, "channels": 3, "parallelism": "replicas only (no exchange step)"},
+            "roofline": {"bound": "hbm", "achieved": round(alg / avg_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / avg_us / 1e3 / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "kernel": "k_pairs_stats_lds", "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2),
+                         "note": "read-once bytes; the kernel is FP64-VALU bound (roofline_valu)"},
+            "roofline_valu": valu_block, "ranks": ranks, "cpu_baseline": cpu}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4", "cfg4std", "welford", "energy"])
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4", "cfg4std", "welford", "energy", "linearity", "linearitystd"])
     ap.add_argument("--stacks", type=int, default=0, help="distinct resident stacks merged round-robin (0 = 4 for cfg2 / cfg2rand, 1 otherwise)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -424,6 +550,9 @@ def main():
 
     if a.workload in ("welford", "energy"):          # single-GPU workloads with their own line
         producer_workload(a, dev, rank, world, dist)
+        return
+    if a.workload in ("linearity", "linearitystd"):
+        linearity_workload(a, dev, rank, world, dist)
         return
     from camera_linearity_amd import engine
     from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark

@@ -1200,6 +1200,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     __shared__ __attribute__((aligned(16))) char lds[16 * 768];
     __shared__ uint32_t s_bad[4];
     constexpr bool DEFER = MAP == 2;                               // MAP 2: the element map of MAP 0, all U stores of a unit issued together at its end
+    constexpr bool PIPE = MAP == 3;                                // MAP 3: the element map of MAP 0, the gathers of frame bundle b + 1 issued under the accumulation of bundle b
     constexpr bool WGMAP = MAP == 1;
     constexpr uint32_t SLOT = WGMAP ? 4u * kSub : kSub;            // element distance between a wave's consecutive slots
     constexpr uint32_t UNIT = U * SLOT;                            // elements per unit (group: U*128, chunk: U*512)
@@ -1260,6 +1261,64 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
         const uint32_t next_off = (unit + ustride) * UNIT;                                   // scalar: byte offset of the next unit in every frame
         double* og = a.out_val + static_cast<int64_t>(unit) * UNIT + wave_el;                // scalar base of the wave's output in this unit
         double held[DEFER ? U : 1][2];
+        if constexpr (PIPE) {
+            // software-pipelined gathers (VERDICT r2 item 7 / DESIGN 9.1): two sets of gathered {w, w g} pairs; the ds_read_b128 of the next
+            // bundle of HM_FB frames (of this or the next sub-unit) are in flight while the current bundle's add / fma chain runs
+            constexpr int NB = (NF + HM_FB - 1) / HM_FB;
+            double2 T[2][HM_FB][2];
+            auto issue = [&](int s_, int b_, double2 (&dst)[HM_FB][2]) {
+#pragma unroll
+                for (int f = 0; f < HM_FB; ++f) {
+                    if (b_ * HM_FB + f < NF) {
+                        const reg_t r = cur[b_ * HM_FB + f][s_];
+                        dst[f][0] = *reinterpret_cast<const double2*>(lds + (__umul24(static_cast<uint32_t>(r & 255u), 48u) + off[(2 * s_) % 3]));
+                        dst[f][1] = *reinterpret_cast<const double2*>(lds + (__umul24(static_cast<uint32_t>(r >> 8), 48u) + off[(2 * s_ + 1) % 3]));
+                    }
+                }
+                if constexpr (REFILL) {                     // PF == 0: the bytes just turned into addresses make room for the next unit's
+#pragma unroll
+                    for (int f = 0; f < HM_FB; ++f)
+                        if (b_ * HM_FB + f < NF)
+                            cur[b_ * HM_FB + f][s_] = ld_u16_buf(frame_rsrc(static_cast<const uint8_t*>(a.frame[b_ * HM_FB + f]) + a.in_off), lane2 + SLOT * s_, next_off);
+                }
+            };
+            issue(0, 0, T[0]);
+#pragma unroll
+            for (int s = 0; s < U; ++s) {
+                double S[2], acc[2];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int gi = s * NB + b;
+                    if (gi + 1 < U * NB) issue((gi + 1) / NB, (gi + 1) % NB, T[(gi + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int f = 0; f < HM_FB; ++f) {
+                        if (b * HM_FB + f < NF) {
+                            const double it = a.inv_t[b * HM_FB + f];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const double2 t = T[gi & 1][f][j];
+                                if (b * HM_FB + f == 0) { S[j] = t.x; acc[j] = t.y * it; }
+                                else {
+                                    S[j] += t.x;                               // exposure_series.py:340
+                                    acc[j] = fma(t.y, it, acc[j]);             // :388 numerator
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { HM_PIN(S[j]); HM_PIN(acc[j]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                double v0, v1;
+                if (fastdiv) { v0 = div_inrange(acc[0], S[0]); v1 = div_inrange(acc[1], S[1]); }
+                else { v0 = acc[0] / S[0]; v1 = acc[1] / S[1]; }
+                store2(og + SLOT * s, lane16, v0, v1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             double S[2], acc[2];
@@ -1849,14 +1908,18 @@ struct Val3Cfg { int u, pf, map; };
 // Late round 2: U = 4 with the second register set (115 VGPRs at N = 7) beats U = 2 by 1.3-1.9 us on three boxes, fast and slow (same-process A/B,
 // shared outputs: 130.2 / 130.3 / 136.4 against 132.1 / 132.0 / 137.9 us, profiles/r02h_ab_val3_u4.log) - 512 contiguous bytes per frame and 4 KB of
 // output per wave iteration; U = 5, 6, 8 and issuing a unit's stores together at its end (MAP = 2) are slower.
-constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{4, 1, 0} : Val3Cfg{3, 0, 0}; }
+// Round 3: software-pipelined gathers (MAP = 3: the ds_read_b128 of the next bundle of 4 frames in flight under the current bundle's add / fma
+// chain, two sets of gathered values, 158 VGPRs = 3 waves/SIMD at N = 7) are 2.0 us faster than MAP = 0 in three same-process A/B runs with
+// shared output buffers on two boxes (129.25 / 126.1 / 128.5 against 131.3 / 128.1 / 130.2 us, profiles/r03_ab_pipe_n7_box*.json) and make no
+// difference for N = 15 (<3, 0, 3> 105.1 against 105.2 us at 133 instead of 82 VGPRs; profiles/r03_ab_pipe_n15_box1.json), which keeps MAP = 0.
+constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{4, 1, 3} : Val3Cfg{3, 0, 0}; }
 static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
     c = val3_default(n_frames);
     if (variant == 0) return true;
     variant %= 10000;                                     // (tuning builds: W * 10000 + 7UPM also sets the workgroups per CU, launch_val3_cfg)
     if (variant < 7000 || variant >= 8000 || n_frames != HM_TUNE_NF) return false;
     c.u = (variant / 100) % 10; c.pf = (variant / 10) % 10; c.map = variant % 10;
-    return c.u >= 1 && c.u <= 8 && c.pf <= 1 && c.map <= 2;
+    return c.u >= 1 && c.u <= 8 && c.pf <= 1 && c.map <= 3;
 }
 #if HM_TUNE_NF != 0
 #include "../../tools/hm_merge_priv_launch.inc"
@@ -1908,6 +1971,10 @@ static int launch_val3(const MergeK& k, hipStream_t st) {
             case 312: return launch_val3_cfg<NF, 3, 1, 2>(k, st);
             case 412: return launch_val3_cfg<NF, 4, 1, 2>(k, st);
             case 410: return launch_val3_cfg<NF, 4, 1, 0>(k, st);
+            case 413: return launch_val3_cfg<NF, 4, 1, 3>(k, st);
+            case 213: return launch_val3_cfg<NF, 2, 1, 3>(k, st);
+            case 303: return launch_val3_cfg<NF, 3, 0, 3>(k, st);
+            case 313: return launch_val3_cfg<NF, 3, 1, 3>(k, st);
             case 402: return launch_val3_cfg<NF, 4, 0, 2>(k, st);
             case 400: return launch_val3_cfg<NF, 4, 0, 0>(k, st);
             case 510: return launch_val3_cfg<NF, 5, 1, 0>(k, st);

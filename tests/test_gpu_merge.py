@@ -894,7 +894,7 @@ def test_headline_kernel_steady_state(eng):
     frames, _, t = synthetic_stack_device(23, n, H, W, device="cuda")
     icrf, _ = synthetic_icrf()
     plan = eng.plan_merge(frames, t, icrf)
-    assert plan.kernels == "merge_u8_val3<N=7,U=4,PF=1,MAP=0>"
+    assert plan.kernels == "merge_u8_val3<N=7,U=4,PF=1,MAP=3>"
     plan.launch()
     val = plan.outputs["val"]
     gen = eng.plan_merge(frames, t, icrf, variant=-1)
@@ -934,7 +934,7 @@ def test_config5_shape_eight_resident_stacks(eng):
     torch.cuda.synchronize()
     sums = set()
     for k, (p, (frames, t)) in enumerate(zip(plans, stacks)):
-        assert p.kernels == "merge_u8_val3<N=7,U=4,PF=1,MAP=0>"
+        assert p.kernels == "merge_u8_val3<N=7,U=4,PF=1,MAP=3>"
         r0 = 37 * k
         ref = orc.merge([f[r0:r0 + 32].cpu().numpy() for f in frames], t, icrf)
         close(host(p.outputs["val"][r0:r0 + 32]), ref["val"], VAL_RTOL)
@@ -965,7 +965,7 @@ def test_fast_division_fallback_branches(eng):
     with np.errstate(all="ignore"):
         for name, icrf, t in cases:
             plan = eng.plan_merge(fr, t, icrf)
-            assert plan.kernels.startswith("merge_u8_val3<N=7,U=4,PF=1,MAP=0>"), name
+            assert plan.kernels.startswith("merge_u8_val3<N=7,U=4,PF=1,MAP=3>"), name
             plan.launch()
             gen = eng.merge(fr, t, icrf, variant=-1)["val"]
             a_, b_ = plan.outputs["val"], gen

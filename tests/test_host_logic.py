@@ -269,11 +269,11 @@ def test_merge_dispatch_table():
     merge_u8_val3 with the per-N configuration, std / flat / sum-of-weights to merge_u8_fast(_std), N > 16 and C != 3 to the
     run-time-N kernels, float64 frames to merge_f64_*, unaligned frames to merge_generic, dark maps add the fix-up pass."""
     from camera_linearity_amd import _native as nat
-    assert _describe(7) == (0, "merge_u8_val3<N=7,U=4,PF=1,MAP=0>")
-    assert _describe(8)[1] == "merge_u8_val3<N=8,U=4,PF=1,MAP=0>"
+    assert _describe(7) == (0, "merge_u8_val3<N=7,U=4,PF=1,MAP=3>")
+    assert _describe(8)[1] == "merge_u8_val3<N=8,U=4,PF=1,MAP=3>"
     assert _describe(15)[1] == "merge_u8_val3<N=15,U=3,PF=0,MAP=0>"
     assert _describe(7, H=4, W=8)[1] == "merge_generic<f64in=0,std=0>"                      # 96 elements: less than one group
-    assert _describe(7, H=5, W=64)[1] == "merge_u8_val3<N=7,U=4,PF=1,MAP=0> + merge_generic<f64in=0,std=0>"   # 960 = 1 unit of 512 + tail
+    assert _describe(7, H=5, W=64)[1] == "merge_u8_val3<N=7,U=4,PF=1,MAP=3> + merge_generic<f64in=0,std=0>"   # 960 = 1 unit of 512 + tail
     assert _describe(7, std=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0>"
     assert _describe(7, std=True, flat=True, darks=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=1,sum_w=0> + merge_fixup_hot<f64in=0,std=1>"
     # with a queue workspace the hot-pixel pass is scan -> balanced patch (-> the old pass, gated on the queue's overflow flag)
@@ -305,7 +305,7 @@ def test_merge_splits_huge_tiles_into_row_bands():
     rc, names = _describe(7, H=65538, W=21846)                     # 65538 * 65538 = 4 295 229 444 elements > 2^32
     assert rc == 0
     parts = names.split(" + ")
-    assert parts[0] == "merge_u8_val3<N=7,U=4,PF=1,MAP=0>" and parts.count("merge_u8_val3<N=7,U=4,PF=1,MAP=0>") == 2, names
+    assert parts[0] == "merge_u8_val3<N=7,U=4,PF=1,MAP=3>" and parts.count("merge_u8_val3<N=7,U=4,PF=1,MAP=3>") == 2, names
     assert all(p.startswith("merge_u8_val3") or p.startswith("merge_generic") for p in parts)
     rc, names = _describe(7, H=65538, W=21846, std=True, darks=True)
     assert rc == 0 and names.count("merge_u8_fast_std") == 2 and names.count("merge_fixup_hot") == 2

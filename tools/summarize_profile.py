@@ -99,4 +99,12 @@ if len(sys.argv) > 5 and "traffic" in out:
     rec[sys.argv[5]] = {"hbm_bytes_per_launch": out["traffic"]["hbm_bytes_per_launch"], "ratio_to_algorithmic": out["traffic"]["ratio_to_algorithmic"],
                         "kernel": merge["name"], "commit": sys.argv[6] if len(sys.argv) > 6 else "?", "source": f"profiles/{tag}_rocprof_summary.json"}
     json.dump(rec, open(tp, "w"), indent=1)
+if len(sys.argv) > 5 and "pairs_stats" in kname and "SQ_INSTS_VALU" in counters:
+    import pathlib
+    tp = pathlib.Path(f"profiles/{os.environ.get('HM_ROUND', 'r03')}_linearity_valu.json")
+    rec = json.load(open(tp)) if tp.exists() else {}
+    rec[sys.argv[5]] = {"valu_wave_instructions_per_launch": counters["SQ_INSTS_VALU"], "kernel": merge["name"], "avg_us_under_profiler": merge["avg_us"],
+                        "valu_busy_frac": (counters.get("SQ_ACTIVE_INST_VALU", 0) / counters["SQ_WAVE_CYCLES"]) if counters.get("SQ_WAVE_CYCLES") else None,
+                        "commit": sys.argv[6] if len(sys.argv) > 6 else "?", "source": f"profiles/{tag}_rocprof_summary.json"}
+    json.dump(rec, open(tp, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("merge_kernel", "launch", "counters_per_launch", "traffic", "derived", "roofline") if k in out}, indent=1))
