@@ -31,6 +31,16 @@ inline unsigned stream_grid(int64_t work_items, int block, int blocks_per_cu) {
     return static_cast<unsigned>(need < cap ? need : cap);
 }
 
+// grid for a kernel whose WAVES stride over `wave_items` equal work items: the cap of stream_grid(), then as few workgroups as keep the
+// number of items per wave the same for every wave (12 288 items on 8 192 waves = half of the waves do two and the others wait for them)
+inline unsigned balanced_wave_grid(int64_t wave_items, int waves_per_block, int blocks_per_cu) {
+    const int64_t cap_waves = static_cast<int64_t>(cu_count()) * blocks_per_cu * waves_per_block;
+    if (wave_items <= 0) return 1;
+    const int64_t iters = (wave_items + cap_waves - 1) / cap_waves;
+    const int64_t waves = (wave_items + iters - 1) / iters;
+    return static_cast<unsigned>((waves + waves_per_block - 1) / waves_per_block);
+}
+
 // Gaussian weight of the merge, measurand.py:615: w = e ** (-30 (v - 0.5)^2) with dv = v - 0.5. One definition for every
 // kernel that evaluates it analytically (float64 frames), so they agree bit for bit.
 #ifdef HM_FAKE_EXP          /* timing experiment only: removes the cost of exp() */

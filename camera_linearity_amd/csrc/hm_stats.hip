@@ -645,11 +645,11 @@ __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, doub
 // SX / SY: the first / second operand has a std image (compile-time, so that no load sits behind a branch: the waits in front of an
 // iteration's arithmetic can then leave the NEXT iteration's loads in flight); statistics are weighted when either has one.
 constexpr int kPairUN = 2;                     // 64-element chunks per wave iteration (sb and sb + stride)
-template <bool STD>
-__device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mult, const double (&xv)[kPairUN], const double (&xs)[kPairUN],
-                                             const double (&yv)[kPairUN], const double (&ys)[kPairUN]) {
+template <bool STD, int UN = kPairUN>
+__device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mult, const double (&xv)[UN], const double (&xs)[UN],
+                                             const double (&yv)[UN], const double (&ys)[UN]) {
 #pragma unroll
-    for (int u = 0; u < kPairUN; ++u) {
+    for (int u = 0; u < UN; ++u) {
         double av, as = 0.0, wa, rv, rs = 0.0, wr;
         bool special = false;
         pair_terms<STD, false>(xv[u], xs[u], yv[u], ys[u], mult, av, as, wa, rv, rs, wr, special);
@@ -658,19 +658,19 @@ __device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mul
         acc_add_pair<STD>(st[0], av, wa, as);
         acc_add_pair<STD>(st[1], rv, wr, rs);
     }
-    if ((it & (kMomBlock / kPairUN - 1)) == kMomBlock / kPairUN - 1) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }
+    if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }   // every kMomBlock elements, whatever UN
 }
 
 // the wave's last, partial chunks (from iteration `it` at element sb on), then the final fold
-template <bool SX, bool SY>
+template <bool SX, bool SY, int UN = kPairUN>
 __device__ __forceinline__ void pair_tail(MomAcc (&st)[2], int it, int64_t sb, const double* x, const double* sx, const double* y,
                                           const double* sy, double mult, int64_t n, int64_t stride, uint32_t lane, Mom (&mine)[2]) {
     constexpr bool STD = SX || SY;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    for (; sb < n; sb += kPairUN * stride, ++it) {
-        double xv[kPairUN], yv[kPairUN], xs[kPairUN], ys[kPairUN];
+    for (; sb < n; sb += UN * stride, ++it) {
+        double xv[UN], yv[UN], xs[UN], ys[UN];
 #pragma unroll
-        for (int u = 0; u < kPairUN; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const int64_t q = sb + u * stride + lane;
             const bool ok = q < n;
             const int64_t qc = ok ? q : n - 1;                                   // a valid address; the element enters as NaN
@@ -680,17 +680,18 @@ __device__ __forceinline__ void pair_tail(MomAcc (&st)[2], int it, int64_t sb, c
             ys[u] = SY ? sy[qc] : 0.0;
             if (STD) xs[u] = ok ? xs[u] : nan;
         }
-        pair_process<STD>(st, it, mult, xv, xs, yv, ys);
+        pair_process<STD, UN>(st, it, mult, xv, xs, yv, ys);
     }
     mine[0] = acc_finish<true>(st[0], STD);
     mine[1] = acc_finish<true>(st[1], STD);
 }
 
-template <bool SX, bool SY, bool NT>
+// UN = 64-element chunks per wave iteration. Without stds a lane has only two 8-byte loads per chunk in flight: the per-pair kernel then
+// takes four chunks per iteration (same element order per lane, same fold points: the same bits as UN = 2)
+template <bool SX, bool SY, bool NT, int UN = kPairUN>
 __device__ __forceinline__ void pair_loop(const double* x, const double* sx, const double* y, const double* sy, double mult, int64_t n,
                                           int64_t sb0, int64_t stride, uint32_t lane, Mom (&mine)[2]) {
     constexpr bool STD = SX || SY;
-    constexpr int UN = kPairUN;
     MomAcc st[2] = {acc_zero(), acc_zero()};                                   // absolute | relative difference
     const uint32_t lo = lane * 8u;
     int it = 0;
@@ -715,14 +716,14 @@ __device__ __forceinline__ void pair_loop(const double* x, const double* sx, con
     if (whole(sb)) load(sb, xa, sxa, ya, sya);
     while (whole(sb)) {
         load(whole(sb + step) ? sb + step : sb, xb, sxb, yb, syb);
-        pair_process<STD>(st, it, mult, xa, sxa, ya, sya);
+        pair_process<STD, UN>(st, it, mult, xa, sxa, ya, sya);
         ++it; sb += step;
         if (!whole(sb)) break;
         load(whole(sb + step) ? sb + step : sb, xa, sxa, ya, sya);
-        pair_process<STD>(st, it, mult, xb, sxb, yb, syb);
+        pair_process<STD, UN>(st, it, mult, xb, sxb, yb, syb);
         ++it; sb += step;
     }
-    pair_tail<SX, SY>(st, it, sb, x, sx, y, sy, mult, n, stride, lane, mine);
+    pair_tail<SX, SY, UN>(st, it, sb, x, sx, y, sy, mult, n, stride, lane, mine);
 }
 
 template <bool SX, bool SY>
@@ -734,7 +735,10 @@ __global__ __launch_bounds__(256) void k_pair_stats(const double* __restrict__ x
     const int64_t sb0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     const int ct = static_cast<int>((sb0 + lane) % C);
     Mom mine[2];
-    pair_loop<SX, SY, true>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
+#ifndef HM_PAIR_UN_NOSTD
+#define HM_PAIR_UN_NOSTD 4
+#endif
+    pair_loop<SX, SY, true, (SX || SY) ? kPairUN : HM_PAIR_UN_NOSTD>(x, sx, y, sy, mult, n, sb0, stride, lane, mine);
     block_merge_store<2>(mine, ct, partial);
 }
 

@@ -172,6 +172,31 @@ def test_hot_pixel_filter_standalone(eng):
         assert np.array_equal(host(outs), refs)
 
 
+@pytest.mark.parametrize("density", [1e-3, 0.3, 1.0])
+@pytest.mark.parametrize("k", [3, 5])
+def test_hot_pixel_filter_burst_and_tail(eng, density, k):
+    """The standalone filter's burst kernel (whole 4 KB-per-wave spans, hot elements patched by their own lane) plus the chunk-by-chunk
+    kernel for the ragged rest: 67 x 129 x 3 = 25 929 elements are 6 spans + a tail for uint8 data and 50 spans + a tail for float64
+    data; sparse, dense and all-hot uint8 maps; a misaligned view (16-byte alignment lost: everything through the old kernel)."""
+    rng = np.random.default_rng(int(1000 * density) + k)
+    h, w = 67, 129
+    x = rng.integers(0, 256, size=(h, w, 3)).astype(np.uint8)
+    xs = rng.random((h, w, 3))
+    dark = rng.integers(0, 20, size=(h, w, 3)).astype(np.uint8)
+    dark[rng.random((h, w, 3)) < density] = 200
+    thr = 0.1
+    dmap = orc.unit_from_u8(dark)
+    ref = orc.hot_pixel_filter(x.astype(np.float64), dmap, thr, k)
+    assert np.array_equal(host(eng.hot_pixel_filter(dev(x), dev(dark), thr, k)).astype(np.float64), ref)
+    refs = orc.hot_pixel_filter(xs, dmap, thr, k)
+    assert np.array_equal(host(eng.hot_pixel_filter(dev(xs), dev(dark), thr, k)), refs)            # float64 data, uint8 map: burst kernel
+    big = torch.zeros(x.size + 16, dtype=torch.uint8, device="cuda")
+    view = big[3:3 + x.size].view(h, w, 3)
+    view.copy_(dev(x))
+    assert not view.data_ptr() % 16 == 0
+    assert np.array_equal(host(eng.hot_pixel_filter(view, dev(dark), thr, k)).astype(np.float64), ref)
+
+
 # ------------------------------------------------------------------ seeded stacks vs the oracle
 @pytest.mark.parametrize("n,h,w", [(1, 5, 7), (2, 16, 16), (7, 33, 29), (7, 64, 128), (15, 24, 40), (16, 9, 11),
                                    (17, 8, 8), (32, 4, 6), (24, 40, 33), (32, 31, 50)])

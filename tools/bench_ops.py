@@ -46,6 +46,7 @@ CASES = {
     "__pow__ scalar 2.2 with std (general exponent)": (lambda: engine.pow_scalar(v2, sd, 2.2), E * 32),
     "normalize_by_map (flat field, with std)": (lambda: engine.normalize_by_map(v, sd, flat, flat_std, m, s), E * 41),
     "hot_pixel_filter u8 (dark map, 3x3 median)": (lambda: engine.hot_pixel_filter(dn, dark, 0.05, 3), E * 3),
+    "hot_pixel_filter f64 (dark map, 3x3 median)": (lambda: engine.hot_pixel_filter(v, dark, 0.05, 3), E * 17),
     "roi_mean u8 (flat ROI 20 %)": (lambda: engine.roi_mean(flat, x0, x1, y0, y1), (x1 - x0) * (y1 - y0) * 3),
     "channel_statistics weighted (one pass)": (lambda: engine.channel_statistics(v, sd), E * 16),
     "channel_statistics unweighted (one pass)": (lambda: engine.channel_statistics(v, None), E * 8),
