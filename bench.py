@@ -119,7 +119,12 @@ def _kernel_key(name):
     """('merge_u8_val3', (7, 4, 1, 0)) from either the demangled symbol rocprof prints or the library's own description."""
     import re
     m = re.search(r"(merge_\w+)\s*<([^>]*)>", name or "")
-    return (m.group(1), tuple(int(x) for x in re.findall(r"-?\d+", m.group(2)))) if m else None
+    if not m:
+        return None
+    nums = tuple(int(x) for x in re.findall(r"-?\d+", m.group(2)))
+    # merge_u8_val3's four parameters are all integers in both spellings; the other kernels' bool parameters print as true / false in
+    # the demangled symbol and as 0 / 1 in the library's description: compare their name and first parameter (N or C)
+    return (m.group(1), nums if m.group(1) == "merge_u8_val3" else nums[:1])
 
 
 def measured_traffic(workload, kernel=None):

@@ -40,6 +40,40 @@ __global__ __launch_bounds__(256) void k_weight_f64(const double* __restrict__ v
     }
 }
 
+// the same in the burst access shape: a wave owns 512-element chunks, issues its four 16-byte loads per lane back to back,
+// evaluates its 8 elements and writes w and dw stream by stream. profiles/r03i_weightf64_rocprof_summary.md is the kernel above on a
+// 4096 x 4096 x 3 frame: 16 VGPRs, one 8-byte load in flight per lane, VALU active 2.7 % of the wave cycles, 0.59 of 8 TB/s - bound by its
+// access shape, not by exp().
+constexpr int kWBurst = 4;
+constexpr int kWChunk = 128 * kWBurst;
+template <bool HAS_W, bool HAS_DW>
+__global__ __launch_bounds__(256) void k_weight_f64_burst(const double* __restrict__ v, double* __restrict__ w, double* __restrict__ dw, int64_t n_chunks) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t cstride = static_cast<int64_t>(gridDim.x) * 4;
+    for (int64_t c = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6); c < n_chunks; c += cstride) {
+        const int64_t b = c * kWChunk;
+        f64x2 x[kWBurst], y[kWBurst], dy[kWBurst];
+#pragma unroll
+        for (int k = 0; k < kWBurst; ++k) x[k] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(v + b + 128 * k) + lane);
+#pragma unroll
+        for (int k = 0; k < kWBurst; ++k) {
+            const double d0 = x[k].x - 0.5, d1 = x[k].y - 0.5;
+            const double y0 = gauss_weight(d0), y1 = gauss_weight(d1);      // measurand.py:615
+            y[k] = f64x2{y0, y1};
+            dy[k] = f64x2{(-60.0 * d0) * y0, (-60.0 * d1) * y1};           // measurand.py:616
+        }
+        if constexpr (HAS_W) {
+#pragma unroll
+            for (int k = 0; k < kWBurst; ++k) __builtin_nontemporal_store(y[k], reinterpret_cast<f64x2*>(w + b + 128 * k) + lane);
+        }
+        if constexpr (HAS_DW) {
+#pragma unroll
+            for (int k = 0; k < kWBurst; ++k) __builtin_nontemporal_store(dy[k], reinterpret_cast<f64x2*>(dw + b + 128 * k) + lane);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_weight_u8(const uint8_t* __restrict__ dn, const double* __restrict__ w_lut,
                                                    const double* __restrict__ dw_lut, double* __restrict__ w,
                                                    double* __restrict__ dw, int64_t n) {
@@ -247,6 +281,19 @@ extern "C" int hm_gaussian_weight_f64(const double* v, double* w, double* dw, in
     if (n < 0 || (n > 0 && (!v || (!w && !dw)))) return HM_EINVAL;
     if (n == 0) return HM_OK;
     if (!aligned(v, 8) || (w && !aligned(w, 8)) || (dw && !aligned(dw, 8))) return HM_EALIGN;
+    // whole 512-element chunks of 16-byte aligned buffers in the burst shape, the rest element by element
+    const int64_t n_chunks = (aligned(v, 16) && (!w || aligned(w, 16)) && (!dw || aligned(dw, 16))) ? n / kWChunk : 0;
+    if (n_chunks > 0) {
+        const unsigned bgrid = balanced_wave_grid(n_chunks, 4, 12);
+        if (w && dw) hipLaunchKernelGGL((k_weight_f64_burst<true, true>), dim3(bgrid), dim3(256), 0, as_stream(stream), v, w, dw, n_chunks);
+        else if (w) hipLaunchKernelGGL((k_weight_f64_burst<true, false>), dim3(bgrid), dim3(256), 0, as_stream(stream), v, w, dw, n_chunks);
+        else hipLaunchKernelGGL((k_weight_f64_burst<false, true>), dim3(bgrid), dim3(256), 0, as_stream(stream), v, w, dw, n_chunks);
+        const int64_t done = n_chunks * kWChunk;
+        if (done == n) return launch_status();
+        v += done; n -= done;
+        if (w) w += done;
+        if (dw) dw += done;
+    }
     hipLaunchKernelGGL(k_weight_f64, dim3(stream_grid(n, 256, 8)), dim3(256), 0, as_stream(stream), v, w, dw, n);
     return launch_status();
 }

@@ -1627,6 +1627,24 @@ __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
         return __builtin_nontemporal_load(reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(base) + lane16));
     };
 
+#ifndef HM_F64_PREFETCH
+#define HM_F64_PREFETCH 0    // std mode, N <= kF64Keep: the next group's frame values loaded (second register set) before the current group's exp()s.
+                             // Round 3, measured and left off: the kernel sits at its 3-waves/SIMD register budget (166 VGPRs) and the second set spills
+                             // (1 890 us against 1 305 us on 7 x 4096 x 4096 x 3 + std); at 2 waves/SIMD 1 565 us, without the kept weights 1 456 us,
+                             // that at 4 waves/SIMD 1 745 us (profiles/r03_ab_f64std_prefetch.log). As with the uint8 std kernels, more loads in
+                             // flight per wave do not help a kernel that already covers bandwidth x latency across its waves.
+#endif
+    constexpr bool PRE = STD && HM_F64_PREFETCH;
+    const bool keep_regs = STD && N <= kF64Keep;                                  // wave-uniform
+    f64x2 vpre[PRE ? kF64Keep : 1];
+    if constexpr (PRE) {
+        const uint32_t g0 = blockIdx.x * WPB + wave;
+        if (keep_regs && g0 < n_groups) {
+#pragma unroll
+            for (int i = 0; i < kF64Keep; ++i)
+                if (i < N) vpre[i] = ld2(static_cast<const double*>(a.frame[i]) + a.in_off + static_cast<int64_t>(g0) * kSub);
+        }
+    }
     for (uint32_t g = blockIdx.x * WPB + wave; g < n_groups; g += gstride) {
         const int64_t sbase = static_cast<int64_t>(g) * kSub;
         const int64_t ibase = a.in_off + sbase;
@@ -1703,9 +1721,18 @@ __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
                 f64x2 v[kF64Keep];
                 constexpr bool KEEPW = HM_F64_KEEP_W && !FLAT;   // (with the flat-field operands live as well the kept weights spill)
                 double wk[KEEPW ? kF64Keep : 1][2];              // pass 1's weights, reused by pass 2 (one exp() per element-frame instead of two)
+                if constexpr (PRE) {
+                    // (unconditional: past the last group it re-reads the current one and the values are dropped - a branch around the loads
+                    // would make the compiler wait for them before this group's arithmetic)
+                    const int64_t nbase = a.in_off + static_cast<int64_t>(g + gstride < n_groups ? g + gstride : g) * kSub;
 #pragma unroll
-                for (int i = 0; i < kF64Keep; ++i)
-                    if (i < N) v[i] = ld2(static_cast<const double*>(a.frame[i]) + ibase);
+                    for (int i = 0; i < kF64Keep; ++i)
+                        if (i < N) { v[i] = vpre[i]; vpre[i] = ld2(static_cast<const double*>(a.frame[i]) + nbase); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kF64Keep; ++i)
+                        if (i < N) v[i] = ld2(static_cast<const double*>(a.frame[i]) + ibase);
+                }
 #pragma unroll
                 for (int i = 0; i < kF64Keep; ++i) {
                     if (i < N) {

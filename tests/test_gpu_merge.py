@@ -155,6 +155,19 @@ def test_gaussian_weight(eng, golden):
     w, dw = eng.gaussian_weight(dev(dn))
     assert np.array_equal(host(w), r["w_lut"]) and np.array_equal(host(dw), r["dw_lut"])   # LUT path: bit-identical
     assert np.array_equal(host(eng.u8_to_unit(dev(dn))), dn.astype(np.float64) / 255)
+    # analytic weights of a frame that is several 512-element burst chunks plus a ragged rest, and of a view that is not 16-byte aligned
+    # (element-by-element kernel): the same bits from both kernels, 1e-14 from np.e ** x
+    rng = np.random.default_rng(6)
+    v = rng.random((37, 71, 3)) * 1.2 - 0.1
+    w, dw = eng.gaussian_weight(dev(v))
+    ow, odw = orc.gaussian_weight(v)
+    close(host(w), ow, 1e-14)
+    close(host(dw), odw, 1e-14)
+    big = torch.zeros(v.size + 1, dtype=torch.float64, device="cuda")
+    view = big[1:].view(v.shape)
+    view.copy_(dev(v))
+    w2, dw2 = eng.gaussian_weight(view)
+    assert torch.equal(w2, w) and torch.equal(dw2, dw)
 
 
 def test_hot_pixel_filter_standalone(eng):
