@@ -1,12 +1,11 @@
 #!/bin/bash
-# GPU-box smoke sequence: full -m gpu suite, smoke(), default bench and the secondary workloads; logs under gpurun_out/<tag>_*
+# final verification of a round (GPU box): tests, smoke, standalone kernels, the default bench line, the N > 1 rehearsal (two ranks sharing
+# the one GPU, gloo carrying the barrier, no torchrun on the command line). usage: tools/gpu_check.sh <tag>
 set -o pipefail
-TAG=${1:-r2}
-O=gpurun_out
-mkdir -p $O
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/${TAG}_pytest_gpu.log
+TAG=${1:-r03k}; O=gpurun_out; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -q -m gpu > $O/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/${TAG}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/${TAG}_smoke.log
-python bench.py > $O/${TAG}_bench_default.log 2>&1; echo "bench rc=$?"; tail -1 $O/${TAG}_bench_default.log
-for W in ${WORKLOADS:-cfg3 cfg3std cfg3flat cfg3hot cfg4 cfg4std cfg5 cfg2rand}; do
-  timeout -k 10 600 python bench.py --workload $W --steps 50 --warmup 5 > $O/${TAG}_bench_$W.log 2>&1; echo "$W rc=$?"; tail -1 $O/${TAG}_bench_$W.log | cut -c1-1500
-done
+python tools/bench_ops.py > $O/${TAG}_bench_ops.log 2>&1; cp $O/bench_ops.json $O/${TAG}_bench_ops.json; echo "bench_ops rc=$?"
+python bench.py > $O/${TAG}_bench_default.log 2>&1; echo "bench rc=$?"; tail -1 $O/${TAG}_bench_default.log | cut -c1-700
+python bench.py --gpus 2 --share-device --dist-backend gloo > $O/${TAG}_bench_2ranks.log 2>&1; echo "2 ranks rc=$?"; tail -1 $O/${TAG}_bench_2ranks.log | cut -c1-400
+python bench.py --gpus 2 --share-device --dist-backend gloo --workload cfg4 > $O/${TAG}_bench_cfg4_2ranks.log 2>&1; echo "cfg4 2 ranks rc=$?"; tail -1 $O/${TAG}_bench_cfg4_2ranks.log | cut -c1-400
