@@ -2180,8 +2180,18 @@ static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t
     hipLaunchKernelGGL(merge_scan_hot, dim3(stream_grid(chunks, kScanBlock, 1)), dim3(kScanBlock), 0, st, k, ws, capacity);
     int rc = launch_status();
     if (rc != HM_OK) return rc;
-    const unsigned grid = stream_grid(k.n_elems, 256, 8);
+    // The grid is what the chip holds AT ONCE (the kernel's occupancy: 3-6 workgroups per CU, by registers): every workgroup is then
+    // resident from the start and a sparse queue costs the latency of one element. A grid of 8 per CU ran its workgroups in three
+    // rounds at 3 resident per CU - 57-65 us for 35 000 queued elements, each round the same dependent chain of memory round trips.
     const int keep = patch_keep_bytes(f64in, k.n_frames, k.median_k);
+    const void* fn;
+    if (f64in) fn = with_std ? reinterpret_cast<const void*>(merge_patch_hot<true, true>) : reinterpret_cast<const void*>(merge_patch_hot<true, false>);
+    else       fn = with_std ? reinterpret_cast<const void*>(merge_patch_hot<false, true>) : reinterpret_cast<const void*>(merge_patch_hot<false, false>);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, static_cast<size_t>(keep)) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    if (const int e = tune_env("HM_TUNE_PATCH_WG_PER_CU")) per_cu = e;
+    const unsigned grid = stream_grid(k.n_elems, 256, per_cu);
 #define HM_PATCH(K, F, S) hipLaunchKernelGGL((K<F, S>), dim3(grid), dim3(256), keep, st, k, static_cast<const uint32_t*>(ws))
 #define HM_PATCH4(K) { if (f64in) { if (with_std) HM_PATCH(K, true, true); else HM_PATCH(K, true, false); } \
                        else       { if (with_std) HM_PATCH(K, false, true); else HM_PATCH(K, false, false); } }
