@@ -62,6 +62,7 @@ _SIGNATURES = {
     "hm_linearize_f64": (C.c_int, [C.c_void_p] * 7 + [C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "hm_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
     "hm_merge_hot_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "hm_merge_hot_workspace_min_bytes": (C.c_size_t, [C.c_int64]),
     "hm_merge_algorithmic_bytes": (C.c_int64, [C.POINTER(MergeArgs)]),
     "hm_merge_describe": (C.c_int, [C.POINTER(MergeArgs), C.c_char_p, C.c_int]),
     "hm_hot_pixel_filter_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,

@@ -371,10 +371,16 @@ __device__ __forceinline__ uint32_t scan_chunk_hotbits(const MergeK& a, int64_t 
     return hotbits;
 }
 
-// Hot-element queue in the caller's workspace (hm_merge_args.hot_workspace): two counters, then the element indices.
+// Hot-element queue in the caller's workspace (hm_merge_args.hot_workspace), uint32 words:
 //   ws[0] = number of queued elements, ws[1] = overflow flag (the queue was too small: merge_patch_hot goes over the whole tile),
-//   ws[4 ...] = element indices relative to row0 (uint32: the queue path requires fewer than 2^32 elements per call).
-constexpr int kHotQueueHeader = 4;       // uint32 words before the first queue entry (16 bytes)
+//   ws[2] = number of pieces the scan wrote (its workgroups x rounds), ws[3] unused;
+//   ws[4 .. 4 + 2 T)  piece table, T = hot_piece_slots(n_elems): {queue offset, count} of piece p - a piece is what one scan workgroup
+//                     queued in one round, 65 536 consecutive elements of the image, and p counts them in IMAGE order; the pieces land in
+//                     the queue in the order of their atomics, the table lets the patch kernel walk them in image order;
+//   ws[4 + 2 T ...]   element indices relative to row0 (uint32: the queue path requires fewer than 2^32 elements per call).
+constexpr int kHotQueueHeader = 4;       // uint32 words before the piece table (16 bytes)
+constexpr int kHotPiecesLds = 2048;      // pieces the patch kernel can order in LDS (134 M elements per call); beyond that it walks the queue as it lies
+__host__ __device__ inline uint32_t hot_piece_slots(int64_t n_elems) { return static_cast<uint32_t>(n_elems / 65536 + 1 + 1024); }
 
 // merge_fixup_hot: every lane scans 16 consecutive elements of every distinct dark map; elements with at least one hot
 // frame are recomputed, one at a time, by the wave. This is the path WITHOUT a workspace: one element per wave at a time
@@ -423,6 +429,8 @@ __global__ __launch_bounds__(256) void merge_fixup_hot(const MergeK a) {
 constexpr int kScanRound = 4;
 constexpr int kScanBlock = 1024;
 __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uint32_t* ws, uint32_t capacity) {
+    uint32_t* const table = ws + kHotQueueHeader;
+    uint32_t* const queue = table + 2u * hot_piece_slots(a.n_elems);
     __shared__ uint32_t s_tot[kScanBlock / 64];
     __shared__ uint32_t s_base, s_ok;
     constexpr uint32_t WPB = kScanBlock / 64;
@@ -520,12 +528,16 @@ __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uin
                 }
             }
             s_base = base; s_ok = ok;
+            const uint32_t piece = static_cast<uint32_t>(r * gridDim.x + blockIdx.x);          // image order
+            table[2u * piece] = ok ? base : 0u;
+            table[2u * piece + 1u] = ok ? total : 0u;
+            if (blockIdx.x == 0 && r == 0) ws[2] = static_cast<uint32_t>(rounds * gridDim.x);
         }
         __syncthreads();
         if (s_ok && mine) {
             uint32_t off = s_base + (incl - mine);
             for (uint32_t w = 0; w < wave; ++w) off += s_tot[w];
-            uint32_t* q = ws + kHotQueueHeader + off;
+            uint32_t* q = queue + off;
 #pragma unroll
             for (int k = 0; k < kScanRound; ++k) {
                 uint32_t bits = hb[k];
@@ -702,20 +714,74 @@ __global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uin
     if (overflow == 0u && count == 0u) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    // A workgroup owns a CONTIGUOUS piece of the queue (4 B entries per iteration, `iters` iterations), and workgroups that run on the
-    // same XCD (blockIdx % 8: round-robin dispatch) own neighbouring pieces - entries that are neighbours in the queue are neighbours in
-    // the image (merge_scan_hot), so the rows they share are fetched into ONE L2 once.
+    // Blocks of B consecutive entries - consecutive in IMAGE order: the pieces are walked through the scan's piece table - are dealt
+    // iteration by iteration: in iteration `it` the logical workgroup l takes blocks (it * G + l) * 4 + wave, and workgroups that run on
+    // the same XCD (blockIdx % 8: round-robin dispatch) are neighbours in l. At any moment one XCD works on ONE run of image rows, and
+    // the lines its hot elements share (rows r - 1, r, r + 1 of every frame) are requested from one L2 at about the same time: at a
+    // density of 5e-2 a workgroup that owned a contiguous part of the queue over all its iterations fetched every line 2.3 times
+    // (profiles/r03e_hot5e2_patch_rocprof_summary.md; 2 270 -> 1 820 us per merge with the interleaved order, r03m_ab_patch_order.log).
+    // HM_PATCH_ORDER 1 = that first mapping.
+#ifndef HM_PATCH_ORDER
+#define HM_PATCH_ORDER 0
+#endif
+    const uint32_t* const table = ws + kHotQueueHeader;
+    const uint32_t* const queue = table + 2u * hot_piece_slots(a.n_elems);
     const uint32_t iters = B ? (count + n_waves * B - 1u) / (n_waves * B) : 0u;
     const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
     const uint32_t logical = gridDim.x % 8u == 0u ? (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
-    const uint64_t wg_first = static_cast<uint64_t>(logical) * 4u * B * iters;
-    if (overflow == 0u && wg_first >= count) return;
+    auto entry_of = [&](uint32_t it) -> uint64_t {
+        if (HM_PATCH_ORDER == 1) return static_cast<uint64_t>(logical) * 4u * B * iters + (static_cast<uint64_t>(it) * 4u + wave) * B + lane;
+        return ((static_cast<uint64_t>(it) * gridDim.x + logical) * 4u + wave) * B + lane;
+    };
+    if (overflow == 0u && static_cast<uint64_t>(logical) * 4u * B * (HM_PATCH_ORDER == 1 ? iters : 1u) >= count) return;
+    // image-order position -> queue slot: exclusive prefix of the piece counts in LDS (one piece = 8 bytes of table per 65 536 elements)
+    __shared__ uint32_t s_pref[kHotPiecesLds + 1], s_off[kHotPiecesLds], s_wsum[4];
+    const uint32_t n_pieces = __builtin_amdgcn_readfirstlane(ws[2]);
+    const bool ordered = overflow == 0u && n_pieces <= static_cast<uint32_t>(kHotPiecesLds) && HM_PATCH_ORDER == 0;
+    if (ordered) {
+        constexpr uint32_t PER = kHotPiecesLds / 256;
+        uint32_t cnt[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t pc = threadIdx.x * PER + k;
+            cnt[k] = pc < n_pieces ? table[2u * pc + 1u] : 0u;
+            if (pc < n_pieces) s_off[pc] = table[2u * pc];
+            sum += cnt[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= static_cast<uint32_t>(d)) incl += up;
+        }
+        if (lane == 63u) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t pc = threadIdx.x * PER + k;
+            if (pc <= n_pieces) s_pref[pc] = run;
+            run += cnt[k];
+        }
+        if (threadIdx.x == 255) s_pref[kHotPiecesLds] = run;
+        __syncthreads();
+    }
+    auto slot_of = [&](uint64_t pos) -> uint64_t {                  // pos < count
+        if (!ordered) return pos;
+        uint32_t lo = 0, hi = n_pieces;                               // the piece p with s_pref[p] <= pos < s_pref[p + 1]
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= static_cast<uint32_t>(pos)) lo = mid; else hi = mid;
+        }
+        return static_cast<uint64_t>(s_off[lo]) + (static_cast<uint32_t>(pos) - s_pref[lo]);
+    };
     // the first entry and its dark bytes are fetched while the workgroup builds its tables (a short queue is one entry per lane:
     // its latency is the kernel's duration)
     int64_t e_first = 0;
     uint32_t hot_first = 0;
-    if (overflow == 0u && lane < B && wg_first + wave * B + lane < count) {
-        e_first = static_cast<int64_t>(ws[kHotQueueHeader + wg_first + wave * B + lane]);
+    if (overflow == 0u && lane < B && entry_of(0) < count) {
+        e_first = static_cast<int64_t>(queue[slot_of(entry_of(0))]);
         hot_first = lane_hotmask(a, a.in_off + e_first);
     }
     fill_plain_tables<F64IN, STD>(a, t_w, t_dw, t_g, t_d);
@@ -730,12 +796,12 @@ __global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uin
         return;
     }
     for (uint32_t it = 0; it < iters; ++it) {
-        const uint64_t q = wg_first + (static_cast<uint64_t>(it) * 4u + wave) * B + lane;
+        const uint64_t q = entry_of(it);
         if (lane < B && q < count) {
             int64_t e = e_first;
             uint32_t hotmask = hot_first;
             if (it != 0u) {
-                e = static_cast<int64_t>(ws[kHotQueueHeader + q]);
+                e = static_cast<int64_t>(queue[slot_of(q)]);
                 hotmask = lane_hotmask(a, a.in_off + e);
             }
             patch_element<F64IN, STD>(a, t_w, t_dw, t_g, t_d, keep_lds, e, hotmask);
@@ -2169,13 +2235,14 @@ static int launch_fixup(const MergeK& k, bool f64in, bool with_std, hipStream_t 
 // the queue path of the hot-pixel pass: zero the counters, scan the dark maps into the queue, patch the queued elements;
 // on overflow merge_patch_hot goes over the whole tile instead of the queue (a queue that was too small costs time, never correctness)
 static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t* ws, size_t ws_bytes, hipStream_t st) {
-    const size_t words = ws_bytes / 4;
-    const uint32_t capacity = static_cast<uint32_t>(words - kHotQueueHeader > 0xffffffffull ? 0xffffffffull : words - kHotQueueHeader);
+    const size_t head = static_cast<size_t>(kHotQueueHeader) + 2u * hot_piece_slots(k.n_elems);     // counters + piece table, in words
+    const size_t words = ws_bytes / 4 - head;
+    const uint32_t capacity = static_cast<uint32_t>(words > 0xffffffffull ? 0xffffffffull : words);
     if (describe_only("merge_scan_hot")) {
         describe_only("merge_patch_hot<f64in=%d,std=%d>", f64in, with_std);
         return HM_OK;
     }
-    if (hipMemsetAsync(ws, 0, kHotQueueHeader * 4, st) != hipSuccess) return HM_ELAUNCH;
+    if (hipMemsetAsync(ws, 0, head * 4, st) != hipSuccess) return HM_ELAUNCH;
     const int64_t chunks = (k.n_elems + 15) / 16;
     hipLaunchKernelGGL(merge_scan_hot, dim3(stream_grid(chunks, kScanBlock, 1)), dim3(kScanBlock), 0, st, k, ws, capacity);
     int rc = launch_status();
@@ -2224,14 +2291,19 @@ extern "C" int64_t hm_merge_algorithmic_bytes(const hm_merge_args* g) {
     return per * E;
 }
 
-// Workspace of the hot-pixel queue for a call that produces n_elems = rows * W * C output elements: 16 bytes of counters +
-// one uint32 per queued element. The recommended size holds a quarter of the elements (a dark map with 25 % hot pixels);
-// any size from hm_merge_hot_workspace_bytes(1) up is accepted - a queue that overflows makes the patch kernel go over the whole tile.
+// Workspace of the hot-pixel queue for a call that produces n_elems = rows * W * C output elements: 16 bytes of counters, the piece
+// table (8 bytes per 65 536 elements + 8 KB) and one uint32 per queued element. The recommended size holds a quarter of the elements
+// (a dark map with 25 % hot pixels); a workspace with room for at least one entry (hm_merge_hot_workspace_min_bytes) is accepted - a
+// queue that overflows makes the patch kernel go over the whole tile; a smaller one selects the workspace-free pass.
+extern "C" size_t hm_merge_hot_workspace_min_bytes(int64_t n_elems) {
+    if (n_elems < 1) n_elems = 1;
+    return (static_cast<size_t>(hm::kHotQueueHeader) + 2u * hm::hot_piece_slots(n_elems) + 1u) * 4;
+}
 extern "C" size_t hm_merge_hot_workspace_bytes(int64_t n_elems) {
     if (n_elems < 1) n_elems = 1;
     int64_t entries = n_elems / 4;
     if (entries < 4096) entries = n_elems < 4096 ? n_elems : 4096;
-    return static_cast<size_t>(hm::kHotQueueHeader + entries) * 4;
+    return hm_merge_hot_workspace_min_bytes(n_elems) + static_cast<size_t>(entries - 1) * 4;
 }
 
 extern "C" int hm_merge_describe(const hm_merge_args* g, char* buf, int buf_len) {
@@ -2389,7 +2461,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (rc != HM_OK) return rc;
     // ---- hot-pixel fix-up pass (stream-ordered after the streaming pass: it overwrites the affected elements)
     if (hot) {
-        const bool queue = g->hot_workspace && g->hot_workspace_bytes >= hm_merge_hot_workspace_bytes(1) && aligned(g->hot_workspace, 16) &&
+        const bool queue = g->hot_workspace && g->hot_workspace_bytes >= hm_merge_hot_workspace_min_bytes(E) && aligned(g->hot_workspace, 16) &&
                            E < (int64_t{1} << 32);
         rc = queue ? launch_hot_queue(k, f64in, with_std, static_cast<uint32_t*>(g->hot_workspace), g->hot_workspace_bytes, st)
                    : launch_fixup(k, f64in, with_std, st);

@@ -148,15 +148,18 @@ typedef struct hm_merge_args {
     /* hot-pixel queue (optional; used when darks_u8 is set). With a workspace the dark maps are scanned into a queue of hot
      * element indices and a balanced second kernel patches one queued element per lane - its cost follows the number of
      * hot elements, dense maps included. NULL: the scan recomputes hot elements one at a time per wave (sparse maps only).
-     * Device memory, 16-byte aligned, hm_merge_hot_workspace_bytes(rows * W * C) bytes recommended (smaller is legal: a
-     * queue that overflows falls back to the NULL path); owned by this call until it has completed on `stream`.          */
+     * Device memory, 16-byte aligned, hm_merge_hot_workspace_bytes(rows * W * C) bytes recommended (down to
+     * hm_merge_hot_workspace_min_bytes() is legal: a queue that overflows makes the patch kernel test every element itself;
+     * anything smaller selects the NULL path); owned by this call until it has completed on `stream`.                      */
     void*    hot_workspace;
     size_t   hot_workspace_bytes;
 } hm_merge_args;
 
 int hm_merge(const hm_merge_args* args /*[host]*/, void* stream);
-/* Recommended size of hm_merge_args.hot_workspace for a call with n_elems = rows * W * C output elements. */
+/* Recommended / smallest accepted size of hm_merge_args.hot_workspace for a call with n_elems = rows * W * C output elements
+ * (counters + a table of 8 bytes per 65 536 elements + the queue: a quarter of the elements / one entry). */
 size_t hm_merge_hot_workspace_bytes(int64_t n_elems);
+size_t hm_merge_hot_workspace_min_bytes(int64_t n_elems);
 
 /* Algorithmic HBM bytes one hm_merge call moves: every input byte once, every output
  * byte once, LUTs excluded. Used by bench.py for roofline.achieved. */

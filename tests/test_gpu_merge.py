@@ -343,9 +343,9 @@ def test_hot_pixel_queue_at_every_density(eng, density, shared_map):
 
 
 def test_hot_pixel_queue_smallest_workspace(eng):
-    """Any workspace from hm_merge_hot_workspace_bytes(1) = 20 bytes up is legal: a one-entry queue overflows on the second hot
-    element and the gated fallback pass produces the image."""
-    import ctypes as C
+    """Any workspace from hm_merge_hot_workspace_min_bytes() up is legal: a one-entry queue overflows on the second hot element and
+    the patch kernel goes over the whole tile instead; one byte less selects the workspace-free pass. Same bits every way."""
+    from camera_linearity_amd import _native as nat
     n, h, w = 3, 40, 33
     frames, stds, t = orc.synthetic_stack(78, n, h, w, with_std=True)
     icrf, diff = orc.synthetic_icrf()
@@ -353,12 +353,17 @@ def test_hot_pixel_queue_smallest_workspace(eng):
     d = (rng.random((h, w, 3)) < 0.02).astype(np.uint8) * 200
     fr, sd, dk = [dev(f) for f in frames], [dev(s) for s in stds], dev(d)
     plan = eng.plan_merge(fr, t, icrf, diff, sd, darks=[dk] * n, dark_min=[100] * n, median_k=3)
-    small = torch.zeros(32, dtype=torch.uint8, device="cuda")
-    plan.args.hot_workspace, plan.args.hot_workspace_bytes = small.data_ptr(), 20
+    least = int(nat.lib.hm_merge_hot_workspace_min_bytes(h * w * 3))
+    small = torch.zeros(least + 16, dtype=torch.uint8, device="cuda")
+    plan.args.hot_workspace, plan.args.hot_workspace_bytes = small.data_ptr(), least
+    assert "merge_scan_hot" in plan.kernels
     plan.launch()
     torch.cuda.synchronize()
-    words = small.cpu().numpy().view(np.uint32)
+    words = small.cpu().numpy()[:16].view(np.uint32)
     assert words[0] >= 1 and words[1] == 1                 # something was queued, then the queue overflowed
+    plan.args.hot_workspace_bytes = least - 1
+    assert "merge_scan_hot" not in plan.kernels and "merge_fixup_hot" in plan.kernels
+    plan.args.hot_workspace_bytes = least
     old = eng.plan_merge(fr, t, icrf, diff, sd, darks=[dk] * n, dark_min=[100] * n, median_k=3, hot_queue=False)
     old.launch()
     assert torch.equal(plan.outputs["val"], old.outputs["val"]) and torch.equal(plan.outputs["std"], old.outputs["std"])

@@ -279,8 +279,12 @@ def test_merge_dispatch_table():
     # with a queue workspace the hot-pixel pass is scan -> balanced patch (-> the old pass, gated on the queue's overflow flag)
     assert _describe(7, std=True, darks=True, hot_ws=True)[1] == ("merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0> + merge_scan_hot + merge_patch_hot<f64in=0,std=1>"
                                                                  "")
-    assert nat.lib.hm_merge_hot_workspace_bytes(4096 * 4096 * 3) == 16 + 4096 * 4096 * 3      # a quarter of the elements, 4 bytes each
-    assert nat.lib.hm_merge_hot_workspace_bytes(100) == 16 + 400 and nat.lib.hm_merge_hot_workspace_bytes(0) == 20
+    # workspace = 16 bytes of counters + the piece table (8 bytes per 65 536 elements + 1025 spare slots) + 4 bytes per queued element
+    E = 4096 * 4096 * 3
+    slots = E // 65536 + 1 + 1024
+    assert nat.lib.hm_merge_hot_workspace_bytes(E) == 16 + 8 * slots + E                        # queue: a quarter of the elements
+    assert nat.lib.hm_merge_hot_workspace_min_bytes(E) == 16 + 8 * slots + 4                    # room for one entry
+    assert nat.lib.hm_merge_hot_workspace_bytes(100) == 16 + 8 * 1025 + 400 and nat.lib.hm_merge_hot_workspace_min_bytes(0) == 16 + 8 * 1025 + 4
     assert _describe(7, sumw=True)[1] == "merge_u8_fast<N=7,U=2,flat=0,sum_w=1>"
     assert _describe(17)[1] == "merge_u8_loop<C=3,flat=0,sum_w=0>(N=17)"
     assert _describe(7, C=1)[1] == "merge_u8_loop<C=1,flat=0,sum_w=0>(N=7)"
