@@ -62,7 +62,14 @@ struct MergeK {
     int32_t n_frames, C, median_k, has_flat;
     int32_t inv_t_inrange;                 // every 1/exposure in [2^-300, 2^300] (host check; see div_inrange)
     int32_t variant;
+    uint32_t* hot_reset;                   // the hot-pixel queue's four counter words, zeroed by the streaming kernel that runs before the scan
 };
+
+// The queue's counters must be zero when merge_scan_hot starts. A hipMemsetAsync costs two fill kernels (~10 us per call, 1 % of
+// config 3); the streaming kernel that precedes the scan in stream order does it in passing instead (one wave-uniform test per workgroup).
+__device__ __forceinline__ void reset_hot_counters(const MergeK& a) {
+    if (a.hot_reset && blockIdx.x == 0 && threadIdx.x < 4) a.hot_reset[threadIdx.x] = 0u;
+}
 
 __device__ __forceinline__ void elem_to_pixel(const MergeK& a, int64_t e, int64_t& row, int64_t& col, int& c) {
     const int64_t wc = a.W * a.C;
@@ -205,6 +212,7 @@ __device__ __forceinline__ void fill_plain_tables(const MergeK& a, double* t_w, 
 template <bool F64IN, bool STD>
 __global__ __launch_bounds__(256) void merge_generic(const MergeK a) {
     __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
+    reset_hot_counters(a);
     fill_plain_tables<F64IN, STD>(a, t_w, t_dw, t_g, t_d);
     __syncthreads();
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -947,6 +955,7 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
 __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    reset_hot_counters(a);
     constexpr int C = 3;
     constexpr uint32_t GROUP = U * kSub;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1265,6 +1274,7 @@ template <int NF, int U, int PF, int MAP>
 __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     __shared__ __attribute__((aligned(16))) char lds[16 * 768];
     __shared__ uint32_t s_bad[4];
+    reset_hot_counters(a);
     constexpr bool DEFER = MAP == 2;                               // MAP 2: the element map of MAP 0, all U stores of a unit issued together at its end
     constexpr bool PIPE = MAP == 3;                                // MAP 3: the element map of MAP 0, the gathers of frame bundle b + 1 issued under the accumulation of bundle b
     constexpr bool WGMAP = MAP == 1;
@@ -1475,6 +1485,7 @@ constexpr int kLoopChunk = 8;
 template <int C, bool STD, bool FLAT, bool SUMW>
 __device__ __forceinline__ void merge_u8_loop_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    reset_hot_counters(a);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1672,6 +1683,7 @@ __device__ __forceinline__ uint32_t lut_index_f64(double v) {
 template <int C, bool STD, bool FLAT, bool SUMW>
 __device__ __forceinline__ void merge_f64_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    reset_hot_counters(a);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u, lane16 = lane * 16u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2242,7 +2254,7 @@ static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t
         describe_only("merge_patch_hot<f64in=%d,std=%d>", f64in, with_std);
         return HM_OK;
     }
-    if (hipMemsetAsync(ws, 0, head * 4, st) != hipSuccess) return HM_ELAUNCH;
+    // (the counters were zeroed by the streaming kernel of this call - MergeK::hot_reset; the scan writes every table entry it owns)
     const int64_t chunks = (k.n_elems + 15) / 16;
     hipLaunchKernelGGL(merge_scan_hot, dim3(stream_grid(chunks, kScanBlock, 1)), dim3(kScanBlock), 0, st, k, ws, capacity);
     int rc = launch_status();
@@ -2410,6 +2422,9 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     k.inv_t_inrange = 1;
     for (int i = 0; i < N; ++i) k.inv_t_inrange = k.inv_t_inrange && k.inv_t[i] >= 0x1p-300 && k.inv_t[i] <= 0x1p300;
     hipStream_t st = as_stream(stream);
+    const bool hot_queue = hot && g->hot_workspace && g->hot_workspace_bytes >= hm_merge_hot_workspace_min_bytes(g->rows * g->width * C) &&
+                           aligned(g->hot_workspace, 16) && g->rows * g->width * C < (int64_t{1} << 32);
+    k.hot_reset = hot_queue ? static_cast<uint32_t*>(g->hot_workspace) : nullptr;
 
     // ---- streaming pass: fast kernel where eligible, generic kernel otherwise (dark maps are not read here)
     FastCfg cfg;
@@ -2461,9 +2476,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (rc != HM_OK) return rc;
     // ---- hot-pixel fix-up pass (stream-ordered after the streaming pass: it overwrites the affected elements)
     if (hot) {
-        const bool queue = g->hot_workspace && g->hot_workspace_bytes >= hm_merge_hot_workspace_min_bytes(E) && aligned(g->hot_workspace, 16) &&
-                           E < (int64_t{1} << 32);
-        rc = queue ? launch_hot_queue(k, f64in, with_std, static_cast<uint32_t*>(g->hot_workspace), g->hot_workspace_bytes, st)
+        rc = hot_queue ? launch_hot_queue(k, f64in, with_std, static_cast<uint32_t*>(g->hot_workspace), g->hot_workspace_bytes, st)
                    : launch_fixup(k, f64in, with_std, st);
     }
     return rc;
