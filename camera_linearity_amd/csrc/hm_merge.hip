@@ -571,6 +571,9 @@ __global__ __launch_bounds__(kScanBlock) void merge_scan_hot(const MergeK a, uin
 // Pass 1 leaves every frame's (filtered) value in a per-thread LDS column for pass 2; the std medians are taken in pass 2.
 // Other kernel sizes (5, 7) and float64 stacks of more than kPatchF64Frames frames go through merge_one_element<HOT_LANE>.
 // ------------------------------------------------------------------------------------------------
+#ifndef HM_PATCH_HOT_ONLY
+#define HM_PATCH_HOT_ONLY 1             // 1: neighbour loads only in the lanes (and waves) where the frame is hot; 0: select-ed addresses, no branch
+#endif
 constexpr int kPatchFB = 4;             // frames whose nine neighbour loads are issued together (float64 values / stds)
 constexpr int kPatchFBU8 = 8;           // the same for uint8 values (one VGPR each)
 constexpr int kPatchF64Frames = 16;     // float64 stacks: frames kept in LDS between the passes (8 B x 256 threads each)
@@ -616,8 +619,21 @@ __device__ __forceinline__ void patch_element_k3(const MergeK& a, const double* 
             if (i0 + f < N) {
                 const T* fr = static_cast<const T*>(a.frame[i0 + f]) + ei;
                 const bool hot = (hotmask >> (i0 + f)) & 1u;
+#if HM_PATCH_HOT_ONLY
+                // the frame's own element for every lane; its eight neighbours only in the lanes where THIS frame is hot (a wave in
+                // which it is hot nowhere skips them): with one map per frame an element is typically hot in one frame of N
+                const V centre = static_cast<V>(fr[0]);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) p[f][q] = centre;
+                if (hot) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+                        if (q != 4) p[f][q] = static_cast<V>(fr[dy[q / 3] + dx[q % 3]]);
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < 9; ++q) p[f][q] = static_cast<V>(fr[hot ? dy[q / 3] + dx[q % 3] : int64_t{0}]);
+#endif
             }
         }
 #pragma unroll
@@ -646,8 +662,19 @@ __device__ __forceinline__ void patch_element_k3(const MergeK& a, const double* 
                 if (i0 + f < N) {
                     const double* sr = a.sd[i0 + f] + ei;
                     const bool hot = (hotmask >> (i0 + f)) & 1u;
+#if HM_PATCH_HOT_ONLY
+                    const double centre = sr[0];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) sp[f][q] = centre;
+                    if (hot) {
+#pragma unroll
+                        for (int q = 0; q < 9; ++q)
+                            if (q != 4) sp[f][q] = sr[dy[q / 3] + dx[q % 3]];
+                    }
+#else
 #pragma unroll
                     for (int q = 0; q < 9; ++q) sp[f][q] = sr[hot ? dy[q / 3] + dx[q % 3] : int64_t{0}];
+#endif
                 }
             }
         }
