@@ -2293,9 +2293,18 @@ static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t
     const void* fn;
     if (f64in) fn = with_std ? reinterpret_cast<const void*>(merge_patch_hot<true, true>) : reinterpret_cast<const void*>(merge_patch_hot<true, false>);
     else       fn = with_std ? reinterpret_cast<const void*>(merge_patch_hot<false, true>) : reinterpret_cast<const void*>(merge_patch_hot<false, false>);
+    // (the query costs a few microseconds of host time: remembered per kernel and LDS size; a race between threads only repeats it)
+    static struct { const void* fn; int keep, per_cu; } seen[8];
+    static int n_seen = 0;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, static_cast<size_t>(keep)) != hipSuccess || per_cu < 1) per_cu = 2;
-    if (per_cu > 8) per_cu = 8;
+    for (int i = 0; i < n_seen && i < 8; ++i)
+        if (seen[i].fn == fn && seen[i].keep == keep) per_cu = seen[i].per_cu;
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, static_cast<size_t>(keep)) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (per_cu > 8) per_cu = 8;
+        const int slot = n_seen < 8 ? n_seen++ : 7;
+        seen[slot].fn = fn; seen[slot].keep = keep; seen[slot].per_cu = per_cu;
+    }
     if (const int e = tune_env("HM_TUNE_PATCH_WG_PER_CU")) per_cu = e;
     const unsigned grid = stream_grid(k.n_elems, 256, per_cu);
 #define HM_PATCH(K, F, S) hipLaunchKernelGGL((K<F, S>), dim3(grid), dim3(256), keep, st, k, static_cast<const uint32_t*>(ws))
