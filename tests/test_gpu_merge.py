@@ -1044,3 +1044,31 @@ def test_row_tile_set_single_gpu_assembly(eng):
     assert val3.data_ptr() != val.data_ptr() and torch.equal(val3, val)
     with pytest.raises(ValueError):
         parallel.gather_tiles({}, tiles.bounds, world_size=1)
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 4])
+@pytest.mark.parametrize("flat_u8", [True, False])
+def test_normalize_by_map_channels_and_alignment(eng, C, flat_u8):
+    """normalize_by_map for every channel count on an odd-sized frame (37 x 53 x C: the running channel counter of the element-pair
+    loop wraps at every step), uint8 and float64 flat fields, with and without std, and a view that is not 16-byte aligned (scalar
+    accesses). Against the oracle (measurand.py:585-604). (A burst-shaped version of this five-stream kernel was measured in round 3
+    and dropped: 367.7 against 364.5 us on a 4096 x 4096 x 3 frame.)"""
+    rng = np.random.default_rng(40 + C)
+    h, w = 37, 53
+    val, std = rng.random((h, w, C)) + 0.1, 0.01 * (1 + rng.random((h, w, C)))
+    flat = rng.integers(150, 250, (h, w, C)).astype(np.uint8)
+    fval = orc.unit_from_u8(flat) if flat_u8 else 0.6 + 0.3 * rng.random((h, w, C))
+    fstd = 0.002 * (1 + rng.random((h, w, C)))
+    m, s = list(0.7 + 0.1 * rng.random(C)), list(0.002 + 0.001 * rng.random(C))
+    rv, rs = orc.normalize_by_map(val, std, fval, fstd, np.array(m), np.array(s))
+    dflat = dev(flat) if flat_u8 else dev(fval)
+    nv, ns = eng.normalize_by_map(dev(val), dev(std), dflat, dev(fstd), m, s)
+    close(host(nv), rv, 1e-14)
+    close(host(ns), rs, 1e-9)
+    nv2, none = eng.normalize_by_map(dev(val), None, dflat, None, m)
+    assert none is None and torch.equal(nv2, nv)
+    big = torch.zeros(val.size + 1, dtype=torch.float64, device="cuda")
+    view = big[1:].view(val.shape)
+    view.copy_(dev(val))
+    nv3, ns3 = eng.normalize_by_map(view, dev(std), dflat, dev(fstd), m, s)
+    assert torch.equal(nv3, nv) and torch.equal(ns3, ns)
