@@ -270,7 +270,7 @@ def test_merge_row_tiles_with_halo(eng):
     assert np.array_equal(std, host(whole["std"]))
 
 
-@pytest.mark.parametrize("n,k,f64", [(15, 5, False), (9, 7, False), (7, 3, True), (32, 3, False), (3, 5, True)])
+@pytest.mark.parametrize("n,k,f64", [(15, 5, False), (9, 7, False), (7, 3, True), (32, 3, False), (3, 5, True), (20, 3, True), (16, 3, True)])
 def test_hot_pixel_fixup_batches(eng, n, k, f64):
     """The hot-pixel fix-up takes floor(64 / k^2) frames' medians per batch (k = 3: 7, k = 5: 2, k = 7: 1):
     cover several batches, float64 frames, N up to 32, adjacent hot pixels, image corners and edges."""
