@@ -345,7 +345,9 @@ __device__ __forceinline__ double max0_nan_to_zero(double x) {
     asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
     return r;
 }
-template <bool WEIGHTED>
+// LEAN: every lane of the wave already has its shift K (haveK set), so the two selects that look for the first valid element are
+// dead - the caller checks that with one ballot per iteration (pair_process_any). Same bits either way.
+template <bool WEIGHTED, bool LEAN = false>
 __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, double s) {
     bool use;
     if constexpr (WEIGHTED) {
@@ -357,8 +359,10 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
     } else {
         use = v == v;
     }
-    a.K = (!a.haveK && use) ? v : a.K;
-    a.haveK = a.haveK || use;
+    if constexpr (!LEAN) {
+        a.K = (!a.haveK && use) ? v : a.K;
+        a.haveK = a.haveK || use;
+    }
     const double d = use ? v - a.K : 0.0;
     if constexpr (WEIGHTED) {
         const double we = use ? w : 0.0;
@@ -645,7 +649,7 @@ __device__ __forceinline__ void pair_terms(double xv, double xs, double yv, doub
 // SX / SY: the first / second operand has a std image (compile-time, so that no load sits behind a branch: the waits in front of an
 // iteration's arithmetic can then leave the NEXT iteration's loads in flight); statistics are weighted when either has one.
 constexpr int kPairUN = 2;                     // 64-element chunks per wave iteration (sb and sb + stride)
-template <bool STD, int UN = kPairUN>
+template <bool STD, int UN = kPairUN, bool LEAN = false>
 __device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mult, const double (&xv)[UN], const double (&xs)[UN],
                                              const double (&yv)[UN], const double (&ys)[UN]) {
 #pragma unroll
@@ -655,10 +659,25 @@ __device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mul
         pair_terms<STD, false>(xv[u], xs[u], yv[u], ys[u], mult, av, as, wa, rv, rs, wr, special);
         if (__builtin_amdgcn_ballot_w64(special) != 0)                           // a zero / infinite scale or variance somewhere in the wave
             pair_terms<STD, true>(xv[u], xs[u], yv[u], ys[u], mult, av, as, wa, rv, rs, wr, special);
-        acc_add_pair<STD>(st[0], av, wa, as);
-        acc_add_pair<STD>(st[1], rv, wr, rs);
+        acc_add_pair<STD, LEAN>(st[0], av, wa, as);
+        acc_add_pair<STD, LEAN>(st[1], rv, wr, rs);
     }
     if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }   // every kMomBlock elements, whatever UN
+}
+
+// whole chunks only (all 64 lanes active): the lean body once every lane of the wave has seen a valid element of both differences
+// (normally from the first iteration on) - 8 of ~106 VALU instructions per two element-pairs less in a kernel that is VALU-bound
+#ifndef HM_PAIR_LEAN
+#define HM_PAIR_LEAN 1
+#endif
+template <bool STD, int UN = kPairUN>
+__device__ __forceinline__ void pair_process_any(MomAcc (&st)[2], int it, double mult, const double (&xv)[UN], const double (&xs)[UN],
+                                                 const double (&yv)[UN], const double (&ys)[UN]) {
+    // (without std only: with std the all-pairs kernel sits at the 128 VGPRs a 1024-thread workgroup may use and two bodies make it spill)
+    if constexpr (HM_PAIR_LEAN && !STD) {
+        if (__builtin_amdgcn_ballot_w64(st[0].haveK && st[1].haveK) == ~0ull) { pair_process<STD, UN, true>(st, it, mult, xv, xs, yv, ys); return; }
+    }
+    pair_process<STD, UN, false>(st, it, mult, xv, xs, yv, ys);
 }
 
 // the wave's last, partial chunks (from iteration `it` at element sb on), then the final fold
@@ -716,11 +735,11 @@ __device__ __forceinline__ void pair_loop(const double* x, const double* sx, con
     if (whole(sb)) load(sb, xa, sxa, ya, sya);
     while (whole(sb)) {
         load(whole(sb + step) ? sb + step : sb, xb, sxb, yb, syb);
-        pair_process<STD, UN>(st, it, mult, xa, sxa, ya, sya);
+        pair_process_any<STD, UN>(st, it, mult, xa, sxa, ya, sya);
         ++it; sb += step;
         if (!whole(sb)) break;
         load(whole(sb + step) ? sb + step : sb, xa, sxa, ya, sya);
-        pair_process<STD, UN>(st, it, mult, xb, sxb, yb, syb);
+        pair_process_any<STD, UN>(st, it, mult, xb, sxb, yb, syb);
         ++it; sb += step;
     }
     pair_tail<SX, SY, UN>(st, it, sb, x, sx, y, sy, mult, n, stride, lane, mine);
@@ -893,7 +912,7 @@ __global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_
             xs[u] = STD ? *reinterpret_cast<const double*>(sm + osx + u * 512) : 0.0;
             ys[u] = STD ? *reinterpret_cast<const double*>(sm + osy + u * 512) : 0.0;
         }
-        pair_process<STD>(st, it, mult, xv, xs, yv, ys);
+        pair_process_any<STD>(st, it, mult, xv, xs, yv, ys);
     };
     // Whole iterations (sb is the same for every wave of the workgroup, so the trip count is too). Iteration k: the registers hold
     // iteration k + 1 (loaded during iteration k - 1's arithmetic) -> LDS stage (k + 1) % 3; load iteration k + 2; barrier; compute
