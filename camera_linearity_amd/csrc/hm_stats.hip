@@ -487,9 +487,12 @@ __device__ __forceinline__ double recip_inrange(double s, bool& special) {
 // elements all have the same channel ct = first_element % C. A wave walks over 64-element chunks (sb, sb + stride, ...: four per
 // iteration), whole chunks on a select-free path with the next iteration's loads issued before the current one's arithmetic (two
 // register sets, unconditional prefetch: see pair_loop), the last partial ones with their missing elements at weight 0.
+#ifndef HM_STATS_UN_NOSTD
+#define HM_STATS_UN_NOSTD 8
+#endif
 template <bool WEIGHTED>
 __device__ __forceinline__ Mom stats_loop(const double* val, const double* sd, int64_t n, int64_t sb0, int64_t stride, uint32_t lane) {
-    constexpr int UN = 4;                                   // 64-element chunks per iteration
+    constexpr int UN = WEIGHTED ? 4 : HM_STATS_UN_NOSTD;     // 64-element chunks per iteration (one stream: more of them in flight; same fold points)
     MomAcc st = acc_zero();
     const uint32_t lo = lane * 8u;
     int it = 0;
