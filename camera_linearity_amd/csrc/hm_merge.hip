@@ -738,14 +738,14 @@ static int patch_keep_bytes(bool f64in, int n_frames, int median_k) {
 // If the scan raised the overflow flag (more hot elements than the workspace holds: a quarter of the image with the recommended
 // size) the queue is ignored: every lane looks at its own elements' dark bytes and patches the hot ones.
 template <bool F64IN, bool STD>
-__global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uint32_t* ws) {
+__global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uint32_t* ws, uint32_t bmax) {
     __shared__ double t_w[256], t_dw[256], t_g[256 * HM_MAX_CHANNELS], t_d[256 * HM_MAX_CHANNELS];
     extern __shared__ __attribute__((aligned(16))) char keep_lds[];
     const uint32_t count = __builtin_amdgcn_readfirstlane(ws[0]);
     const uint32_t overflow = __builtin_amdgcn_readfirstlane(ws[1]);
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t B = (count + n_waves - 1u) / n_waves;
-    B = B > 64u ? 64u : B;
+    B = B > bmax ? bmax : B;
     if (overflow == 0u && count == 0u) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -2307,7 +2307,9 @@ static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t
     }
     if (const int e = tune_env("HM_TUNE_PATCH_WG_PER_CU")) per_cu = e;
     const unsigned grid = stream_grid(k.n_elems, 256, per_cu);
-#define HM_PATCH(K, F, S) hipLaunchKernelGGL((K<F, S>), dim3(grid), dim3(256), keep, st, k, static_cast<const uint32_t*>(ws))
+    uint32_t bmax = 64;
+    if (const int e = tune_env("HM_TUNE_PATCH_BMAX")) bmax = static_cast<uint32_t>(e);
+#define HM_PATCH(K, F, S) hipLaunchKernelGGL((K<F, S>), dim3(grid), dim3(256), keep, st, k, static_cast<const uint32_t*>(ws), bmax)
 #define HM_PATCH4(K) { if (f64in) { if (with_std) HM_PATCH(K, true, true); else HM_PATCH(K, true, false); } \
                        else       { if (with_std) HM_PATCH(K, false, true); else HM_PATCH(K, false, false); } }
     HM_PATCH4(merge_patch_hot)
