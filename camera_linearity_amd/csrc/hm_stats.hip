@@ -577,18 +577,24 @@ __global__ __launch_bounds__(256) void k_stats_final(const double* __restrict__ 
 // v_rsq_f64, about 26 bits; already the IEEE answer for 0, infinities and NaN) and two Newton steps, kept only when the estimate is a
 // finite non-zero number - 7 / 10 instructions instead of 11 (divide) / ~26 (sqrt + divide).
 __device__ __forceinline__ bool finite_nonzero(double x) { const double ax = fabs(x); return ax > 0.0 && ax < __builtin_huge_val(); }
+// STEPS == 2 (the default) is ONE higher-order step from the 2^-24 hardware estimate instead of two Newton steps - the same or better
+// accuracy in fewer instructions (checked on 2 M operands against long-double references: reciprocal 1 + e + e^2, e = 1 - x r0: 3 instead
+// of 4 instructions, max 1.00 ulp either way; reciprocal square root y0 (1 + e/2 + 3 e^2 / 8), e = 1 - q y0^2: 5 instead of 7 instructions,
+// max 1.25 ulp against 2.19 ulp). Round 3: -5 of 104 VALU instructions per element-pair of the weighted pair statistics.
 template <int STEPS = 2>
 __device__ __forceinline__ double rcp_newton(double x, double r0) {
-    const double r = fma(fma(-x, r0, 1.0), r0, r0);
-    if constexpr (STEPS == 1) return r;
-    return fma(fma(-x, r, 1.0), r, r);
+    const double e = fma(-x, r0, 1.0);
+    if constexpr (STEPS == 1) return fma(e, r0, r0);
+    return fma(r0, fma(e, e, e), r0);
 }
 template <int STEPS = 2>
 __device__ __forceinline__ double rsq_newton(double q, double y0) {
-    const double h = 0.5 * q;
-    const double y = y0 * fma(-h * y0, y0, 1.5);
-    if constexpr (STEPS == 1) return y;
-    return y * fma(-h * y, y, 1.5);
+    if constexpr (STEPS == 1) {
+        const double h = 0.5 * q;
+        return y0 * fma(-h * y0, y0, 1.5);
+    }
+    const double e = fma(-(q * y0), y0, 1.0);
+    return fma(y0, fma(0.375, e, 0.5) * e, y0);
 }
 #ifndef HM_PAIR_NEWTON
 #define HM_PAIR_NEWTON 2
