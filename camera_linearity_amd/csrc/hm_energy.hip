@@ -121,6 +121,16 @@ __global__ __launch_bounds__(256) void k_energy_partial(const EnergyK a) {
 // the four IEEE divisions + square root per pair-pixel: 1 / v_j is formed once per (pixel, frame), 1 / (v_j ratio) is
 // a product, and the weight 1 / sigma is one reciprocal square root. Those products differ from the reference's
 // quotients by an ulp or two per term (tests: 1e-12 relative on the pair results).
+// 1 / sqrt(q) for the weights of the pixel-major kernel: the hardware estimate (about 2^-24) and ONE third-order step,
+// y0 (1 + e/2 + 3 e^2 / 8) with e = 1 - q y0^2 - 8 instructions and at most 1.25 ulp (checked on 2 M operands against long-double
+// references, as for the pair statistics) where the library's rsqrt() costs about twenty; q = 0 / inf keep the estimate (inf / 0).
+__device__ __forceinline__ double rsqrt_third_order(double q) {
+    const double y0 = __builtin_amdgcn_rsq(q);
+    const double e = fma(-(q * y0), y0, 1.0);
+    const double y = fma(y0, fma(0.375, e, 0.5) * e, y0);
+    return __builtin_amdgcn_class(y0, 0x264) ? y0 : y;                  // -inf | -0 | +0 | +inf
+}
+
 template <int N, bool STD>
 __global__ __launch_bounds__(256) void k_energy_pixel(const EnergyK a, const EnergyPairs pr) {
     constexpr int P = N * (N - 1) / 2;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void k_energy_pixel(const EnergyK a, const Ene
                         const double w2 = ratio * s[j];
                         qq = s[i] * s[i] + w2 * w2;                              // :129
                     }
-                    const double w = rsqrt(qq);                                  // 1 / sigma
+                    const double w = rsqrt_third_order(qq);                      // 1 / sigma
                     const bool ok = isfinite(ad) && qq != 0.0 && w == w;         // :133-134, general_functions.py:164
                     if (ok) { num[p] += ad * w; den[p] += w; }
                 } else {
