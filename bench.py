@@ -515,7 +515,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4", "cfg4std", "welford", "energy", "linearity", "linearitystd"])
-    ap.add_argument("--stacks", type=int, default=0, help="distinct resident stacks merged round-robin (0 = 4 for cfg2 / cfg2rand, 1 otherwise)")
+    ap.add_argument("--stacks", type=int, default=0, help="distinct resident stacks merged round-robin (0 = 4 for cfg2 / cfg2rand, 2 for the cfg3 family, 1 otherwise)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the default) or gloo (rehearsal of the N > 1 path on one GPU)")
@@ -571,7 +571,10 @@ def main():
         return
     n, H, W, with_std, corr = WORKLOADS[a.workload]
     icrf, diff = synthetic_icrf()
-    rotate = a.stacks if a.stacks > 0 else (4 if a.workload in ("cfg2", "cfg2rand", "cfg2smooth") else 1)
+    # config 2: four stacks so that no launch finds the previous one's inputs in the 256 MB Infinity Cache; config 3's stacks (4 GB of inputs
+    # each) cannot be cached anyway - two of them average the placement lottery (the same kernel on the same data takes 746-805 us depending on
+    # where its buffers landed) instead of reporting one draw
+    rotate = a.stacks if a.stacks > 0 else (4 if a.workload in ("cfg2", "cfg2rand", "cfg2smooth") else 2 if a.workload in ("cfg3", "cfg3std", "cfg3flat", "cfg3hot") else 1)
     if a.workload == "cfg5":
         rotate = 1
 
