@@ -13,16 +13,16 @@
 //
 // Kernels (hm_merge dispatches; all share one operation sequence per output element, so a result does not depend on
 // which kernel or tiling produced it):
-//   merge_u8_fast / merge_u8_fast_std   C == 3, N <= 16 (compile-time), 2-byte-aligned uint8 frames; the bench path.
+//   merge_u8_val3                       uint8 frames, C == 3, N <= 16 (compile-time), val-only, no extras: the bench kernel (config 2).
+//   merge_u8_fast / merge_u8_fast_std   the same frames with std, flat field or sum-of-weights output (config 3).
 //   merge_u8_loop / merge_u8_loop_std   uint8 frames, run-time N (17..32) and C (1..4): same decomposition, frames in chunks.
 //   merge_f64_val / merge_f64_std       float64 frames (64-bit mode): analytic weight, computed LUT index.
 //   merge_generic     anything else (tails shorter than a group, unaligned tiles, forced by variant < 0):
 //                     one element per thread.
-//   merge_fixup_hot   dark-frame hot pixels (~1e-4 of the image): scans the dark maps and recomputes the
-//                     affected output elements with the k x k medians substituted. Keeping the rare,
-//                     divergent, register-hungry median out of the streaming kernels is worth 5x on
-//                     config 3 (3.6 ms -> under 1 ms); the scan reads each dark byte once, which is the
-//                     d*N term of the algorithmic byte count.
+//   merge_scan_hot + merge_patch_hot    dark-frame hot pixels: the streaming kernels never look at the dark maps; a scan reads every
+//                     distinct map once (the d term of the algorithmic byte count) and queues the hot elements, a second kernel
+//                     recomputes one queued element per lane with the k x k medians substituted (needs the caller's workspace).
+//   merge_fixup_hot   the same pass without a workspace: one hot element per wave at a time (sparse maps only).
 #include "hm_common.h"
 #include <cstdio>
 #include <cstdlib>
