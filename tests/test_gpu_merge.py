@@ -1072,3 +1072,65 @@ def test_normalize_by_map_channels_and_alignment(eng, C, flat_u8):
     view.copy_(dev(val))
     nv3, ns3 = eng.normalize_by_map(view, dev(std), dflat, dev(fstd), m, s)
     assert torch.equal(nv3, nv) and torch.equal(ns3, ns)
+
+
+def test_hot_pixel_queue_randomised_against_the_workspace_free_pass(eng):
+    """80 random configurations - frames 1..32, channels 1..4, uint8 and float64 frames, k = 3 / 5 / 7, maps from sparse to dense, shared
+    and per-frame maps and thresholds, some frames without a map, std / flat / sum-of-weights on and off, whole images and row tiles with
+    halo: the queue pass (scan -> patch per lane) and the workspace-free pass (one hot element per wave) must agree bit for bit."""
+    rng = np.random.default_rng(2026)
+    for case in range(80):
+        n = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 20, 32]))
+        C = int(rng.choice([1, 2, 3, 3, 3, 4]))
+        h, w = int(rng.integers(3, 70)), int(rng.integers(3, 90))
+        k = int(rng.choice([3, 3, 3, 5, 7]))
+        f64 = bool(rng.random() < 0.3)
+        with_std = bool(rng.random() < 0.6)
+        use_flat = bool(rng.random() < 0.3)
+        density = float(rng.choice([0.0, 1e-3, 0.02, 0.3, 1.0]))
+        t = list(1e-3 * 2.0 ** np.arange(n) * (1 + 0.1 * rng.random(n)))
+        frames = [rng.integers(0, 256, (h, w, C)).astype(np.uint8) for _ in range(n)]
+        if f64:
+            frames = [f.astype(np.float64) / 255 + 1e-4 * rng.random((h, w, C)) for f in frames]
+        stds = [0.004 * (1 + rng.random((h, w, C))) for _ in range(n)] if with_std else None
+        icrf = np.linspace(0, 1, 256)[:, None] ** (1.5 + 0.3 * np.arange(C))[None, :]
+        diff = np.gradient(icrf, 2 / 255, axis=0)
+        shared = dev((rng.random((h, w, C)) < density).astype(np.uint8) * 200)
+        darks, mins = [], []
+        for i in range(n):
+            mode = rng.integers(0, 4)
+            if mode == 0:
+                darks.append(None); mins.append(256)
+            elif mode == 1:
+                darks.append(shared); mins.append(100)
+            elif mode == 2:
+                darks.append(shared); mins.append(int(rng.integers(1, 256)))        # the same map with another threshold: a distinct pair
+            else:
+                darks.append(dev((rng.random((h, w, C)) < density).astype(np.uint8) * int(rng.integers(1, 256)))); mins.append(int(rng.integers(1, 200)))
+        if all(d is None for d in darks):
+            darks[0], mins[0] = shared, 100
+        kw = {}
+        if use_flat:
+            kw.update(flat=dev(rng.integers(120, 250, (h, w, C)).astype(np.uint8)), ff_mean=list(0.7 + 0.1 * rng.random(C)))
+            if with_std:
+                kw.update(flat_std=dev(0.002 * (1 + rng.random((h, w, C)))), ff_std_mean=list(0.002 + 0.001 * rng.random(C)))
+        fr = [dev(f) for f in frames]
+        sd = [dev(s) for s in stds] if with_std else None
+        tile = {}
+        if h >= 8 and rng.random() < 0.4:                                               # a row tile with its median halo
+            r0, r1 = sorted(int(x) for x in rng.choice(np.arange(1, h), 2, replace=False))
+            b0, b1 = max(0, r0 - k // 2), min(h, r1 + k // 2)
+            fr = [f[b0:b1] for f in fr]
+            sd = None if sd is None else [s[b0:b1] for s in sd]
+            darks = [None if d is None else d[b0:b1] for d in darks]
+            tile = dict(height=h, row0=r0, rows=r1 - r0, buf_row0=b0)
+            for key in ("flat", "flat_std"):
+                if key in kw:
+                    kw[key] = kw[key][r0:r1]
+        tag = f"case {case}: n={n} C={C} {h}x{w} k={k} f64={f64} std={with_std} flat={use_flat} density={density} tile={tile}"
+        outs = []
+        for queue in (True, False):
+            outs.append(eng.merge(fr, t, icrf, diff if with_std else None, sd, darks=darks, dark_min=mins, median_k=k, want_sum_w=True,
+                                  hot_queue=queue, **kw, **tile))
+        for key in outs[0]:
+            assert torch.equal(outs[0][key].view(torch.int64), outs[1][key].view(torch.int64)), tag + " " + key
