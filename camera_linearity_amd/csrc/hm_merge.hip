@@ -960,6 +960,9 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #ifndef HM_STD_FB
 #define HM_STD_FB 2      // std kernel, pass 2: frames per scheduling bundle
 #endif
+#ifndef HM_VAL3_FLAT_U
+#define HM_VAL3_FLAT_U 2     // sub-units per iteration of merge_u8_val3's flat-field instantiation (N <= 8): 152 us at 134 VGPRs against 156 us at 176 VGPRs with U = 4
+#endif
 #ifndef HM_F64_KEEP_W
 #define HM_F64_KEEP_W 1      // float64-frame std kernel: keep pass 1's weights in registers for pass 2 (N <= 8): one exp() per
 #endif                       // element-frame instead of two; with 3 waves/SIMD 1 385 -> 1 296 us on 7 x 4096 x 4096 x 3 (profiles/r02c_ab_f64std.log)
@@ -1297,10 +1300,16 @@ __device__ __forceinline__ bool entry_inrange(double w, double wg) {
 // A unit (group or chunk) must start on channel 0 for the channel pattern to be a compile-time function of (s, j): its
 // size is a multiple of 3 when U == 3; for U == 2 the unit index advances by a multiple of 3 per iteration (the host
 // launches a multiple of 3 workgroups), so the phase is a per-wave constant folded into the lane's table offsets.
-template <int NF, int U, int PF, int MAP>
+// FLAT (round 3; uint8 flat fields, PF == 1): the val-only flat-field epilogue (val / F) * m of measurand.py:602 - the flat's DNs travel as
+// one more byte stream beside the frames', F = DN / 255 comes from a 2 KB LDS table, the channel means sit in three registers next to
+// the table offsets. Before, a flat field sent the val-only merge to merge_u8_fast (186 us / 0.54 on config 2's stack).
+template <int NF, int U, int PF, int MAP, bool FLAT = false>
 __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     __shared__ __attribute__((aligned(16))) char lds[16 * 768];
     __shared__ uint32_t s_bad[4];
+    __shared__ double t_F[FLAT ? 256 : 1];
+    static_assert(!FLAT || PF == 1, "the flat-field instantiation uses the two-register-set prefetch");
+    constexpr int NS = NF + (FLAT ? 1 : 0);                        // byte streams: the frames (+ the flat field's DNs as stream NF)
     reset_hot_counters(a);
     constexpr bool DEFER = MAP == 2;                               // MAP 2: the element map of MAP 0, all U stores of a unit issued together at its end
     constexpr bool PIPE = MAP == 3;                                // MAP 3: the element map of MAP 0, the gathers of frame bundle b + 1 issued under the accumulation of bundle b
@@ -1321,8 +1330,13 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     // (PF == 1 keeps 32-bit registers filled by zero-extending global loads: with two 16-bit register sets hipcc packs pairs
     // of them into one VGPR with v_perm_b32 at the loop back-edge, i.e. waits for the prefetch it has just issued)
     using reg_t = std::conditional_t<PF == 0, uint16_t, uint32_t>;
-    reg_t RA[NF][U], RB[PF ? NF : 1][PF ? U : 1];
+    reg_t RA[NS][U], RB[PF ? NS : 1][PF ? U : 1];
     auto load_unit = [&](uint32_t unit, auto& dst) {
+        if constexpr (FLAT) {                                      // the flat field covers the OUTPUT rows: no in_off
+            const uint8_t* p = a.flat_u8 + static_cast<int64_t>(unit) * UNIT;
+#pragma unroll
+            for (int s = 0; s < U; ++s) dst[NF][s] = ld_u16(p + SLOT * s + lane2);
+        }
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             if constexpr (PF == 0) {
@@ -1345,6 +1359,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
         reinterpret_cast<double2*>(lds)[q] = double2{w, wg};
         bad = bad || !entry_inrange(w, wg);
     }
+    if constexpr (FLAT) t_F[threadIdx.x] = static_cast<double>(threadIdx.x) / 255.0;     // F = DN / 255 (image_set.py:223)
     const bool wave_bad = __ballot(bad) != 0ull;
     if (lane == 0) s_bad[wave] = wave_bad ? 1u : 0u;
     __syncthreads();
@@ -1357,6 +1372,20 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     const uint32_t p0 = static_cast<uint32_t>((static_cast<uint64_t>(u) * UNIT) % 3u);
     const uint32_t k = (p0 + lane2) % 3u;
     const uint32_t off[3] = {k * 16u, ((k + 1u) % 3u) * 16u, ((k + 2u) % 3u) * 16u};
+    // FLAT: the ROI means of the channels k, k + 1, k + 2 (no per-lane indexing of the kernarg array)
+    double mm[3] = {1.0, 1.0, 1.0};
+    if constexpr (FLAT) {
+        const double m0 = a.ff_mean[0], m1 = a.ff_mean[1], m2 = a.ff_mean[2];
+        mm[0] = k == 0u ? m0 : k == 1u ? m1 : m2;
+        mm[1] = k == 0u ? m1 : k == 1u ? m2 : m0;
+        mm[2] = k == 0u ? m2 : k == 1u ? m0 : m1;
+    }
+    auto flat_epilogue = [&](int s_, reg_t r, double& v0, double& v1) {          // measurand.py:602, as flat_field_math() does it
+        if constexpr (FLAT) {
+            v0 = (v0 / t_F[r & 255u]) * mm[(2 * s_) % 3];
+            v1 = (v1 / t_F[r >> 8]) * mm[(2 * s_ + 1) % 3];
+        }
+    };
 
     // one unit out of `cur`; REFILL (PF == 0 only): fetch the next unit's bytes into the registers this one frees
     auto process = [&](auto refill_tag, uint32_t unit, auto& cur) {
@@ -1417,6 +1446,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
                 double v0, v1;
                 if (fastdiv) { v0 = div_inrange(acc[0], S[0]); v1 = div_inrange(acc[1], S[1]); }
                 else { v0 = acc[0] / S[0]; v1 = acc[1] / S[1]; }
+                flat_epilogue(s, cur[NS - 1][s], v0, v1);
                 store2(og + SLOT * s, lane16, v0, v1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1465,6 +1495,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
             double v0, v1;
             if (fastdiv) { v0 = div_inrange(acc[0], S[0]); v1 = div_inrange(acc[1], S[1]); }
             else { v0 = acc[0] / S[0]; v1 = acc[1] / S[1]; }
+            flat_epilogue(s, cur[NS - 1][s], v0, v1);
             if constexpr (DEFER) { held[s][0] = v0; held[s][1] = v1; }
             else store2(og + SLOT * s, lane16, v0, v1);
             __builtin_amdgcn_sched_barrier(0);
@@ -2063,9 +2094,14 @@ static bool use_val3(int variant, int n_frames, bool with_std, bool extras) {
     Val3Cfg c;
     return !with_std && !extras && val3_variant(variant, n_frames, c);
 }
+// val-only WITH a uint8 flat field (no sum-of-weights output, library default variant): merge_u8_val3's FLAT instantiation
+constexpr Val3Cfg val3_flat_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{HM_VAL3_FLAT_U, 1, 3} : Val3Cfg{2, 1, 0}; }
+static bool use_val3_flat(const MergeK& k, bool with_std) {
+    return !with_std && k.has_flat && k.flat_u8 && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
+}
 static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map == 1 ? 4 : 1) * static_cast<int>(kSub); }
 
-template <int NF, int U, int PF, int MAP>
+template <int NF, int U, int PF, int MAP, bool FLAT = false>
 static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
     const int64_t units = k.n_elems / (U * (MAP == 1 ? 4 : 1) * static_cast<int>(kSub));
     // workgroups per CU (8 are resident). U = 2 (N <= 8): 12 - a grid of 3072 is a multiple of 3 as it stands (2048 had to become 2046) and
@@ -2080,8 +2116,8 @@ static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
     unsigned grid = MAP == 1 ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, wg_per_cu);   // 8 workgroups of 4 waves per CU
     if (U % 3 != 0 && grid >= 3) grid -= grid % 3;          // the unit index must advance by a multiple of 3 per iteration (see the kernel)
     if (grid == 0) grid = 1;
-    if (describe_only("merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;
-    hipLaunchKernelGGL((merge_u8_val3<NF, U, PF, MAP>), dim3(grid), dim3(256), 0, st, k);
+    if (describe_only(FLAT ? "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d,flat=1>" : "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;
+    hipLaunchKernelGGL((merge_u8_val3<NF, U, PF, MAP, FLAT>), dim3(grid), dim3(256), 0, st, k);
     return launch_status();
 }
 template <int NF>
@@ -2165,6 +2201,8 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
         }
         return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256>(k, st);
     }
+    if (use_val3_flat(k, false))
+        return launch_val3_cfg<NF, val3_flat_default(NF).u, val3_flat_default(NF).pf, val3_flat_default(NF).map, true>(k, st);
     if (extras) return launch_extras<NF, false, kUVal, TAB_FUSED>(k, st);
 #if HM_TUNE_NF != 0
     if constexpr (NF == HM_TUNE_NF) {
@@ -2188,7 +2226,8 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
 }
 
 // elements per group of the configuration launch_fast_nf() will really use
-static int fast_group_elems(int n_frames, int variant, const FastCfg& c, bool with_std, bool extras) {
+static int fast_group_elems(int n_frames, int variant, const FastCfg& c, bool with_std, bool extras, bool val3_flat) {
+    if (val3_flat) return val3_unit_elems(val3_flat_default(n_frames));
     { int pu = 0; if (!with_std && !extras && priv_variant(variant, n_frames, pu)) return pu * 120; }     // merge_u8_priv's chunks (tuning builds)
     { Val3Cfg vc; if (!with_std && !extras && val3_variant(variant, n_frames, vc)) return val3_unit_elems(vc); }
     if (with_std) return ((extras || n_frames != HM_TUNE_NF) ? kUStd : c.u) * static_cast<int>(kSub);
@@ -2491,7 +2530,7 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (!fast) {
         rc = launch_generic(k, f64in, with_std, st);
     } else {
-        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : fast_group_elems(N, g->variant, cfg, with_std, flat || g->out_sum_w);
+        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : fast_group_elems(N, g->variant, cfg, with_std, flat || g->out_sum_w, use_val3_flat(k, with_std));
         const int64_t body = (E / grp) * grp;
         if (body > 0) {
             MergeK kb = k;

@@ -1134,3 +1134,34 @@ def test_hot_pixel_queue_randomised_against_the_workspace_free_pass(eng):
                                   hot_queue=queue, **kw, **tile))
         for key in outs[0]:
             assert torch.equal(outs[0][key].view(torch.int64), outs[1][key].view(torch.int64)), tag + " " + key
+
+
+@pytest.mark.parametrize("n", [3, 7, 15])
+def test_val_only_flat_field_kernel(eng, n):
+    """val-only merge with a uint8 flat field = merge_u8_val3's FLAT instantiation (the flat's DNs travel as one more byte stream,
+    (val / F) * m in the epilogue): at 1536 x 2048 x 3 every wave iterates (register ping-pong); bit for bit the generic kernel, two row
+    tiles bit for bit, a band of the oracle; a float64 flat field and a sum-of-weights output keep the older kernel."""
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
+    H, W = 1536, 2048
+    frames, _, t = synthetic_stack_device(60 + n, n, H, W, device="cuda")
+    icrf, _ = synthetic_icrf()
+    flat, _, _ = synthetic_flat_dark(60 + n, H, W, device="cuda")
+    flat[5, 7, 1] = 0                                               # F = 0: inf / NaN exactly where the generic kernel has them
+    m = [0.78, 0.81, 0.8]
+    plan = eng.plan_merge(frames, t, icrf, flat=flat, ff_mean=m)
+    assert plan.kernels.startswith(f"merge_u8_val3<N={n},") and plan.kernels.endswith(",flat=1>")
+    plan.launch()
+    val = plan.outputs["val"]
+    gen = eng.merge(frames, t, icrf, flat=flat, ff_mean=m, variant=-1)["val"]
+    assert torch.equal(val.view(torch.int64), gen.view(torch.int64))
+    cut = 701
+    top = eng.merge([f[:cut] for f in frames], t, icrf, flat=flat[:cut], ff_mean=m, height=H, row0=0, rows=cut, buf_row0=0)["val"]
+    bot = eng.merge([f[cut:] for f in frames], t, icrf, flat=flat[cut:], ff_mean=m, height=H, row0=cut, rows=H - cut, buf_row0=cut)["val"]
+    assert torch.equal(top.view(torch.int64), val[:cut].view(torch.int64)) and torch.equal(bot.view(torch.int64), val[cut:].view(torch.int64))
+    r0 = 640
+    ref = orc.merge([f[r0:r0 + 48].cpu().numpy() for f in frames], t, icrf)["val"]
+    with np.errstate(all="ignore"):
+        want = (ref / orc.unit_from_u8(flat[r0:r0 + 48].cpu().numpy())) * np.array(m)
+    close(host(val[r0:r0 + 48]), want, VAL_RTOL)
+    assert "merge_u8_fast<" in eng.plan_merge(frames, t, icrf, flat=flat.double() / 255, ff_mean=m).kernels
+    assert "merge_u8_fast<" in eng.plan_merge(frames, t, icrf, flat=flat, ff_mean=m, want_sum_w=True).kernels

@@ -286,6 +286,9 @@ def test_merge_dispatch_table():
     assert nat.lib.hm_merge_hot_workspace_min_bytes(E) == 16 + 8 * slots + 4                    # room for one entry
     assert nat.lib.hm_merge_hot_workspace_bytes(100) == 16 + 8 * 1025 + 400 and nat.lib.hm_merge_hot_workspace_min_bytes(0) == 16 + 8 * 1025 + 4
     assert _describe(7, sumw=True)[1] == "merge_u8_fast<N=7,U=2,flat=0,sum_w=1>"
+    assert _describe(7, flat=True)[1] == "merge_u8_val3<N=7,U=2,PF=1,MAP=3,flat=1>"             # val-only with a uint8 flat field: the bench kernel's FLAT instantiation
+    assert _describe(15, flat=True)[1] == "merge_u8_val3<N=15,U=2,PF=1,MAP=0,flat=1>"
+    assert _describe(7, flat=True, sumw=True)[1] == "merge_u8_fast<N=7,U=2,flat=1,sum_w=1>"
     assert _describe(17)[1] == "merge_u8_loop<C=3,flat=0,sum_w=0>(N=17)"
     assert _describe(7, C=1)[1] == "merge_u8_loop<C=1,flat=0,sum_w=0>(N=7)"
     assert _describe(7, f64=True, std=True)[1] == "merge_f64_std<C=3,flat=0,sum_w=0>(N=7)"
