@@ -1303,9 +1303,13 @@ __device__ __forceinline__ bool entry_inrange(double w, double wg) {
 // FLAT (round 3; uint8 flat fields, PF == 1): the val-only flat-field epilogue (val / F) * m of measurand.py:602 - the flat's DNs travel as
 // one more byte stream beside the frames', F = DN / 255 comes from a 2 KB LDS table, the channel means sit in three registers next to
 // the table offsets. Before, a flat field sent the val-only merge to merge_u8_fast (186 us / 0.54 on config 2's stack).
-template <int NF, int U, int PF, int MAP, bool FLAT = false>
+// CH (round 3): 3 = colour (the channel pattern above), 1 = monochrome cameras - one table column, no channel bookkeeping at all; before,
+// every C != 3 stack went to the run-time-N, run-time-C merge_u8_loop (0.62-0.68 val-only on 7 x 4096 x 4096 x 1).
+template <int NF, int U, int PF, int MAP, bool FLAT = false, int CH = 3>
 __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
-    __shared__ __attribute__((aligned(16))) char lds[16 * 768];
+    static_assert(CH == 3 || CH == 1, "colour or monochrome");
+    constexpr uint32_t TS = 16u * CH;                              // bytes of table per DN
+    __shared__ __attribute__((aligned(16))) char lds[16 * 256 * CH];
     __shared__ uint32_t s_bad[4];
     __shared__ double t_F[FLAT ? 256 : 1];
     static_assert(!FLAT || PF == 1, "the flat-field instantiation uses the two-register-set prefetch");
@@ -1353,8 +1357,8 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     if (u < n_units) load_unit(u, RA);                                              // in flight while the tables are built
 
     bool bad = false;
-    for (int q = threadIdx.x; q < 768; q += 256) {
-        const double w = a.w_lut[q / 3];
+    for (int q = threadIdx.x; q < 256 * CH; q += 256) {
+        const double w = a.w_lut[q / CH];
         const double wg = w * a.icrf[q];                                            // (w * g), exposure_series.py:388
         reinterpret_cast<double2*>(lds)[q] = double2{w, wg};
         bad = bad || !entry_inrange(w, wg);
@@ -1369,21 +1373,22 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
 
     // channel of the lane's first element in slot 0: (unit start + wave offset + 2 lane) % 3; the unit start is a
     // per-wave constant mod 3 (see above)
-    const uint32_t p0 = static_cast<uint32_t>((static_cast<uint64_t>(u) * UNIT) % 3u);
-    const uint32_t k = (p0 + lane2) % 3u;
-    const uint32_t off[3] = {k * 16u, ((k + 1u) % 3u) * 16u, ((k + 2u) % 3u) * 16u};
+    const uint32_t p0 = CH == 1 ? 0u : static_cast<uint32_t>((static_cast<uint64_t>(u) * UNIT) % 3u);
+    const uint32_t k = CH == 1 ? 0u : (p0 + lane2) % 3u;
+    const uint32_t off[3] = {k * 16u, CH == 1 ? 0u : ((k + 1u) % 3u) * 16u, CH == 1 ? 0u : ((k + 2u) % 3u) * 16u};
+    auto ci = [](int x) constexpr { return CH == 1 ? 0 : x % 3; };      // which of the three offsets / means element x of a unit uses
     // FLAT: the ROI means of the channels k, k + 1, k + 2 (no per-lane indexing of the kernarg array)
     double mm[3] = {1.0, 1.0, 1.0};
     if constexpr (FLAT) {
-        const double m0 = a.ff_mean[0], m1 = a.ff_mean[1], m2 = a.ff_mean[2];
+        const double m0 = a.ff_mean[0], m1 = CH == 1 ? m0 : a.ff_mean[1], m2 = CH == 1 ? m0 : a.ff_mean[2];
         mm[0] = k == 0u ? m0 : k == 1u ? m1 : m2;
         mm[1] = k == 0u ? m1 : k == 1u ? m2 : m0;
         mm[2] = k == 0u ? m2 : k == 1u ? m0 : m1;
     }
     auto flat_epilogue = [&](int s_, reg_t r, double& v0, double& v1) {          // measurand.py:602, as flat_field_math() does it
         if constexpr (FLAT) {
-            v0 = (v0 / t_F[r & 255u]) * mm[(2 * s_) % 3];
-            v1 = (v1 / t_F[r >> 8]) * mm[(2 * s_ + 1) % 3];
+            v0 = (v0 / t_F[r & 255u]) * mm[ci(2 * s_)];
+            v1 = (v1 / t_F[r >> 8]) * mm[ci(2 * s_ + 1)];
         }
     };
 
@@ -1403,8 +1408,8 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
                 for (int f = 0; f < HM_FB; ++f) {
                     if (b_ * HM_FB + f < NF) {
                         const reg_t r = cur[b_ * HM_FB + f][s_];
-                        dst[f][0] = *reinterpret_cast<const double2*>(lds + (__umul24(static_cast<uint32_t>(r & 255u), 48u) + off[(2 * s_) % 3]));
-                        dst[f][1] = *reinterpret_cast<const double2*>(lds + (__umul24(static_cast<uint32_t>(r >> 8), 48u) + off[(2 * s_ + 1) % 3]));
+                        dst[f][0] = *reinterpret_cast<const double2*>(lds + (__umul24(static_cast<uint32_t>(r & 255u), TS) + off[ci(2 * s_)]));
+                        dst[f][1] = *reinterpret_cast<const double2*>(lds + (__umul24(static_cast<uint32_t>(r >> 8), TS) + off[ci(2 * s_ + 1)]));
                     }
                 }
                 if constexpr (REFILL) {                     // PF == 0: the bytes just turned into addresses make room for the next unit's
@@ -1462,8 +1467,8 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
                 for (int f = 0; f < HM_FB; ++f) {
                     if (i0 + f < NF) {
                         const reg_t r = cur[i0 + f][s];
-                        addr[f][0] = __umul24(static_cast<uint32_t>(r & 255u), 48u) + off[(2 * s) % 3];
-                        addr[f][1] = __umul24(static_cast<uint32_t>(r >> 8), 48u) + off[(2 * s + 1) % 3];
+                        addr[f][0] = __umul24(static_cast<uint32_t>(r & 255u), TS) + off[ci(2 * s)];
+                        addr[f][1] = __umul24(static_cast<uint32_t>(r >> 8), TS) + off[ci(2 * s + 1)];
                     }
                 }
                 if constexpr (REFILL) {
@@ -2096,12 +2101,16 @@ static bool use_val3(int variant, int n_frames, bool with_std, bool extras) {
 }
 // val-only WITH a uint8 flat field (no sum-of-weights output, library default variant): merge_u8_val3's FLAT instantiation
 constexpr Val3Cfg val3_flat_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{HM_VAL3_FLAT_U, 1, 3} : Val3Cfg{2, 1, 0}; }
+// monochrome stacks (C == 1), val-only, at most a uint8 flat field, library default variant: merge_u8_val3's CH = 1 instantiations
+static bool use_val3_mono(const MergeK& k, bool with_std, bool f64in) {
+    return !f64in && k.C == 1 && !with_std && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16 && (!k.has_flat || k.flat_u8);
+}
 static bool use_val3_flat(const MergeK& k, bool with_std) {
     return !with_std && k.has_flat && k.flat_u8 && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
 }
 static int val3_unit_elems(const Val3Cfg& c) { return c.u * (c.map == 1 ? 4 : 1) * static_cast<int>(kSub); }
 
-template <int NF, int U, int PF, int MAP, bool FLAT = false>
+template <int NF, int U, int PF, int MAP, bool FLAT = false, int CH = 3>
 static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
     const int64_t units = k.n_elems / (U * (MAP == 1 ? 4 : 1) * static_cast<int>(kSub));
     // workgroups per CU (8 are resident). U = 2 (N <= 8): 12 - a grid of 3072 is a multiple of 3 as it stands (2048 had to become 2046) and
@@ -2116,8 +2125,9 @@ static int launch_val3_cfg(const MergeK& k, hipStream_t st) {
     unsigned grid = MAP == 1 ? static_cast<unsigned>(units < cu_count() * 8 ? units : cu_count() * 8) : stream_grid(units, 4, wg_per_cu);   // 8 workgroups of 4 waves per CU
     if (U % 3 != 0 && grid >= 3) grid -= grid % 3;          // the unit index must advance by a multiple of 3 per iteration (see the kernel)
     if (grid == 0) grid = 1;
-    if (describe_only(FLAT ? "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d,flat=1>" : "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>", NF, U, PF, MAP)) return HM_OK;
-    hipLaunchKernelGGL((merge_u8_val3<NF, U, PF, MAP, FLAT>), dim3(grid), dim3(256), 0, st, k);
+    if (describe_only(CH == 1 ? (FLAT ? "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d,flat=1,C=1>" : "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d,C=1>")
+                              : (FLAT ? "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d,flat=1>" : "merge_u8_val3<N=%d,U=%d,PF=%d,MAP=%d>"), NF, U, PF, MAP)) return HM_OK;
+    hipLaunchKernelGGL((merge_u8_val3<NF, U, PF, MAP, FLAT, CH>), dim3(grid), dim3(256), 0, st, k);
     return launch_status();
 }
 template <int NF>
@@ -2200,6 +2210,10 @@ static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipS
             return launch_one<NF, 4, TAB_PLAIN, true, false, false, false, 256>(k, st);
         }
         return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256>(k, st);
+    }
+    if (use_val3_mono(k, false, false)) {
+        if (k.has_flat) return launch_val3_cfg<NF, val3_flat_default(NF).u, val3_flat_default(NF).pf, val3_flat_default(NF).map, true, 1>(k, st);
+        return launch_val3_cfg<NF, val3_default(NF).u, val3_default(NF).pf, val3_default(NF).map, false, 1>(k, st);
     }
     if (use_val3_flat(k, false))
         return launch_val3_cfg<NF, val3_flat_default(NF).u, val3_flat_default(NF).pf, val3_flat_default(NF).map, true>(k, st);
@@ -2514,7 +2528,8 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
         cfg = default_cfg(with_std);
     } else if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
     bool fast = g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
-    const bool loop_kernel = f64in || N > 16 || C != 3;         // run-time-N / any-C streaming kernel instead of the N <= 16, C = 3 templates
+    const bool mono_val3 = use_val3_mono(k, with_std, f64in);
+    const bool loop_kernel = (f64in || N > 16 || C != 3) && !mono_val3;         // run-time-N / any-C streaming kernel instead of the N <= 16 templates
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
             fast = f64in ? aligned(static_cast<const double*>(k.frame[i]) + k.in_off, 16)
@@ -2530,7 +2545,8 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     if (!fast) {
         rc = launch_generic(k, f64in, with_std, st);
     } else {
-        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : fast_group_elems(N, g->variant, cfg, with_std, flat || g->out_sum_w, use_val3_flat(k, with_std));
+        const int64_t grp = loop_kernel ? static_cast<int64_t>(kSub) : (mono_val3 ? val3_unit_elems(flat ? val3_flat_default(N) : val3_default(N))
+                                                                                                 : fast_group_elems(N, g->variant, cfg, with_std, flat || g->out_sum_w, use_val3_flat(k, with_std)));
         const int64_t body = (E / grp) * grp;
         if (body > 0) {
             MergeK kb = k;

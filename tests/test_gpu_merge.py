@@ -1165,3 +1165,33 @@ def test_val_only_flat_field_kernel(eng, n):
     close(host(val[r0:r0 + 48]), want, VAL_RTOL)
     assert "merge_u8_fast<" in eng.plan_merge(frames, t, icrf, flat=flat.double() / 255, ff_mean=m).kernels
     assert "merge_u8_fast<" in eng.plan_merge(frames, t, icrf, flat=flat, ff_mean=m, want_sum_w=True).kernels
+
+
+@pytest.mark.parametrize("n", [2, 7, 15])
+def test_monochrome_val_only_kernel(eng, n):
+    """C = 1 (monochrome cameras), val-only, with and without a uint8 flat field = merge_u8_val3's one-column instantiations: a
+    1536 x 2048 x 1 stack (every wave iterates), bit for bit the generic kernel and two row tiles, a band of the oracle."""
+    rng = np.random.default_rng(70 + n)
+    H, W = 1536, 2048
+    t = list(1e-3 * 2.0 ** np.arange(n))
+    g = torch.Generator(device="cuda").manual_seed(70 + n)
+    rad = torch.rand((H, W, 1), generator=g, device="cuda", dtype=torch.float64) * 4
+    frames = [torch.clamp(torch.round(rad * float(ti * 255 / (4 * t[n // 2]))), 0, 255).to(torch.uint8) for ti in t]
+    icrf = np.linspace(0, 1, 256)[:, None] ** 2.2
+    flat = torch.randint(150, 250, (H, W, 1), generator=g, device="cuda", dtype=torch.uint8)
+    for kw in ({}, dict(flat=flat, ff_mean=[0.79])):
+        plan = eng.plan_merge(frames, t, icrf, **kw)
+        assert plan.kernels.startswith(f"merge_u8_val3<N={n},") and plan.kernels.endswith("C=1>"), plan.kernels
+        plan.launch()
+        val = plan.outputs["val"]
+        gen = eng.merge(frames, t, icrf, variant=-1, **kw)["val"]
+        assert torch.equal(val.view(torch.int64), gen.view(torch.int64))
+        cut = 777
+        tkw = (lambda a, b: dict(flat=flat[a:b], ff_mean=[0.79])) if kw else (lambda a, b: {})
+        top = eng.merge([f[:cut] for f in frames], t, icrf, height=H, row0=0, rows=cut, buf_row0=0, **tkw(0, cut))["val"]
+        bot = eng.merge([f[cut:] for f in frames], t, icrf, height=H, row0=cut, rows=H - cut, buf_row0=cut, **tkw(cut, H))["val"]
+        assert torch.equal(top, val[:cut]) and torch.equal(bot, val[cut:])
+        ref = orc.merge([f[100:148].cpu().numpy() for f in frames], t, icrf)["val"]
+        if kw:
+            ref = (ref / orc.unit_from_u8(flat[100:148].cpu().numpy())) * 0.79
+        close(host(val[100:148]), ref, VAL_RTOL)
