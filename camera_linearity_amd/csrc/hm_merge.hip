@@ -982,11 +982,12 @@ constexpr uint32_t kSub = 128;     // elements per sub-unit (64 lanes x 2)
 #define HM_WAVES_ATTR
 #endif
 
-template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
+template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK, int CH = 3>
 __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     reset_hot_counters(a);
-    constexpr int C = 3;
+    static_assert(CH == 3 || (CH == 1 && STD && !FLAT && !SUMW), "monochrome: the std instantiation without extras only");
+    constexpr int C = CH;
     constexpr uint32_t GROUP = U * kSub;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u;
@@ -1071,8 +1072,8 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
 #pragma unroll
         for (int s = 0; s < U; ++s) {
             const int64_t sbase = gbase + kSub * s;                         // scalar
-            const uint32_t c0 = (2u * (g * U + s + lane)) % 3u;
-            const uint32_t c1 = (c0 + 1u) % 3u;
+            const uint32_t c0 = C == 1 ? 0u : (2u * (g * U + s + lane)) % 3u;
+            const uint32_t c1 = C == 1 ? 0u : (c0 + 1u) % 3u;
             const uint32_t coffs[2] = {STD ? c0 * 16u : chan_off<TAB>(c0), STD ? c1 * 16u : chan_off<TAB>(c1)};
             double* ov = a.out_val + sbase;                                   // scalar bases
             double* osw = SUMW ? a.out_sum_w + sbase : nullptr;
@@ -1186,7 +1187,7 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
                         const double2 gd = double2{static_cast<double>(dn + coffs[j]), static_cast<double>(dn + 3u)};
 #else
                         const double2 wdw = t_wdw[dn];
-                        const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * 48u + coffs[j]);
+                        const double2 gd = *reinterpret_cast<const double2*>(t_gd + dn * (16u * C) + coffs[j]);
 #endif
                         const double w = wdw.x, dw = wdw.y, gg = gd.x;
                         const double dg = gd.y * (j == 0 ? sdv.x : sdv.y);                       // measurand.py:512
@@ -1234,9 +1235,9 @@ __global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const Merge
     static_assert(!STD, "std instantiations go through merge_u8_fast_std");
     merge_u8_fast_body<NF, U, TAB, false, PREFETCH, FLAT, SUMW, BLOCK>(a);
 }
-template <int NF, int U, int TAB, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
+template <int NF, int U, int TAB, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK, int CH = 3>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HM_STD_WAVES, HM_STD_WAVES))) void merge_u8_fast_std(const MergeK a) {
-    merge_u8_fast_body<NF, U, TAB, true, PREFETCH, FLAT, SUMW, BLOCK>(a);
+    merge_u8_fast_body<NF, U, TAB, true, PREFETCH, FLAT, SUMW, BLOCK, CH>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2046,13 +2047,14 @@ static bool decode_variant(int variant, bool with_std, FastCfg& c) {
     return true;
 }
 
-template <int NF, int U, int TAB, bool STD, bool PF, bool FLAT, bool SUMW, int BLOCK>
+template <int NF, int U, int TAB, bool STD, bool PF, bool FLAT, bool SUMW, int BLOCK, int CH = 3>
 static int launch_one(const MergeK& k, hipStream_t st) {
     constexpr int lds = (STD ? kStdTabBytes : TabInfo<TAB>::bytes) + (FLAT ? 16 * 256 : 0);
     void (*kernel)(const MergeK);
-    if constexpr (STD) kernel = merge_u8_fast_std<NF, U, TAB, PF, FLAT, SUMW, BLOCK>;
+    if constexpr (STD) kernel = merge_u8_fast_std<NF, U, TAB, PF, FLAT, SUMW, BLOCK, CH>;
     else kernel = merge_u8_fast<NF, U, TAB, false, PF, FLAT, SUMW, BLOCK>;
-    if (describe_only(STD ? "merge_u8_fast_std<N=%d,U=%d,flat=%d,sum_w=%d>" : "merge_u8_fast<N=%d,U=%d,flat=%d,sum_w=%d>", NF, U, FLAT, SUMW)) return HM_OK;
+    if (describe_only(CH == 1 ? "merge_u8_fast_std<N=%d,U=%d,flat=%d,sum_w=%d,C=1>"
+                              : (STD ? "merge_u8_fast_std<N=%d,U=%d,flat=%d,sum_w=%d>" : "merge_u8_fast<N=%d,U=%d,flat=%d,sum_w=%d>"), NF, U, FLAT, SUMW)) return HM_OK;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
     if (const int e = tune_env("HM_TUNE_WG_PER_CU")) per_cu = e;
@@ -2104,6 +2106,10 @@ constexpr Val3Cfg val3_flat_default(int n_frames) { return n_frames <= 8 ? Val3C
 // monochrome stacks (C == 1), val-only, at most a uint8 flat field, library default variant: merge_u8_val3's CH = 1 instantiations
 static bool use_val3_mono(const MergeK& k, bool with_std, bool f64in) {
     return !f64in && k.C == 1 && !with_std && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16 && (!k.has_flat || k.flat_u8);
+}
+// ... and with std, no extras: merge_u8_fast_std's CH = 1 instantiation
+static bool use_fast_std_mono(const MergeK& k, bool with_std, bool f64in) {
+    return !f64in && k.C == 1 && with_std && !k.has_flat && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
 }
 static bool use_val3_flat(const MergeK& k, bool with_std) {
     return !with_std && k.has_flat && k.flat_u8 && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
@@ -2198,6 +2204,7 @@ template <int NF>
 static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipStream_t st) {
     const bool extras = k.has_flat || k.out_sum_w;
     if (with_std) {
+        if (use_fast_std_mono(k, true, false)) return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256, 1>(k, st);
         if (extras) return launch_extras<NF, true, kUStd, TAB_PLAIN>(k, st);
         if constexpr (NF == HM_TUNE_NF) {
             if (c.prefetch) {
@@ -2529,7 +2536,8 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     } else if (!decode_variant(g->variant, with_std, cfg)) return HM_EINVAL;
     bool fast = g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
     const bool mono_val3 = use_val3_mono(k, with_std, f64in);
-    const bool loop_kernel = (f64in || N > 16 || C != 3) && !mono_val3;         // run-time-N / any-C streaming kernel instead of the N <= 16 templates
+    const bool mono_std = use_fast_std_mono(k, with_std, f64in);
+    const bool loop_kernel = (f64in || N > 16 || C != 3) && !mono_val3 && !mono_std;         // run-time-N / any-C streaming kernel instead of the N <= 16 templates
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
             fast = f64in ? aligned(static_cast<const double*>(k.frame[i]) + k.in_off, 16)

@@ -1195,3 +1195,14 @@ def test_monochrome_val_only_kernel(eng, n):
         if kw:
             ref = (ref / orc.unit_from_u8(flat[100:148].cpu().numpy())) * 0.79
         close(host(val[100:148]), ref, VAL_RTOL)
+    # with std: merge_u8_fast_std's one-column instantiation, the same three checks
+    diff = np.gradient(icrf, 2 / 255, axis=0)
+    stds = [0.004 * (1 + torch.rand((H, W, 1), generator=g, device="cuda", dtype=torch.float64)) for _ in range(n)]
+    plan = eng.plan_merge(frames, t, icrf, diff, stds)
+    assert plan.kernels == f"merge_u8_fast_std<N={n},U=1,flat=0,sum_w=0,C=1>", plan.kernels
+    plan.launch()
+    gen = eng.merge(frames, t, icrf, diff, stds, variant=-1)
+    assert torch.equal(plan.outputs["val"], gen["val"]) and torch.equal(plan.outputs["std"], gen["std"])
+    ref = orc.merge([f[100:148].cpu().numpy() for f in frames], t, icrf, diff, stds=[s_[100:148].cpu().numpy() for s_ in stds])
+    close(host(plan.outputs["val"][100:148]), ref["val"], VAL_RTOL)
+    close(host(plan.outputs["std"][100:148]), ref["std"], STD_RTOL)
