@@ -986,7 +986,7 @@ template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW,
 __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     reset_hot_counters(a);
-    static_assert(CH == 3 || (CH == 1 && STD && !FLAT && !SUMW), "monochrome: the std instantiation without extras only");
+    static_assert(CH == 3 || (CH == 1 && STD && !SUMW), "monochrome: the std instantiations (with or without the flat field) only");
     constexpr int C = CH;
     constexpr uint32_t GROUP = U * kSub;
     const uint32_t lane = threadIdx.x & 63u;
@@ -2107,9 +2107,9 @@ constexpr Val3Cfg val3_flat_default(int n_frames) { return n_frames <= 8 ? Val3C
 static bool use_val3_mono(const MergeK& k, bool with_std, bool f64in) {
     return !f64in && k.C == 1 && !with_std && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16 && (!k.has_flat || k.flat_u8);
 }
-// ... and with std, no extras: merge_u8_fast_std's CH = 1 instantiation
+// ... and with std (with or without a flat field): merge_u8_fast_std's CH = 1 instantiations
 static bool use_fast_std_mono(const MergeK& k, bool with_std, bool f64in) {
-    return !f64in && k.C == 1 && with_std && !k.has_flat && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
+    return !f64in && k.C == 1 && with_std && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
 }
 static bool use_val3_flat(const MergeK& k, bool with_std) {
     return !with_std && k.has_flat && k.flat_u8 && !k.out_sum_w && k.variant == 0 && k.n_frames <= 16;
@@ -2204,7 +2204,10 @@ template <int NF>
 static int launch_fast_nf(const MergeK& k, const FastCfg& c, bool with_std, hipStream_t st) {
     const bool extras = k.has_flat || k.out_sum_w;
     if (with_std) {
-        if (use_fast_std_mono(k, true, false)) return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256, 1>(k, st);
+        if (use_fast_std_mono(k, true, false)) {
+            if (k.has_flat) return launch_one<NF, kUStd, TAB_PLAIN, true, true, true, false, 256, 1>(k, st);
+            return launch_one<NF, kUStd, TAB_PLAIN, true, true, false, false, 256, 1>(k, st);
+        }
         if (extras) return launch_extras<NF, true, kUStd, TAB_PLAIN>(k, st);
         if constexpr (NF == HM_TUNE_NF) {
             if (c.prefetch) {

@@ -1206,3 +1206,11 @@ def test_monochrome_val_only_kernel(eng, n):
     ref = orc.merge([f[100:148].cpu().numpy() for f in frames], t, icrf, diff, stds=[s_[100:148].cpu().numpy() for s_ in stds])
     close(host(plan.outputs["val"][100:148]), ref["val"], VAL_RTOL)
     close(host(plan.outputs["std"][100:148]), ref["std"], STD_RTOL)
+    # ... and with the flat field (uint8 and float64 flats): bit for bit the generic kernel
+    fstd = 0.002 * (1 + torch.rand((H, W, 1), generator=g, device="cuda", dtype=torch.float64))
+    for fl in (flat, flat.double() / 255):
+        plan = eng.plan_merge(frames, t, icrf, diff, stds, flat=fl, flat_std=fstd, ff_mean=[0.79], ff_std_mean=[0.002])
+        assert plan.kernels == f"merge_u8_fast_std<N={n},U=1,flat=1,sum_w=0,C=1>", plan.kernels
+        plan.launch()
+        gen = eng.merge(frames, t, icrf, diff, stds, flat=fl, flat_std=fstd, ff_mean=[0.79], ff_std_mean=[0.002], variant=-1)
+        assert torch.equal(plan.outputs["val"], gen["val"]) and torch.equal(plan.outputs["std"], gen["std"])

@@ -293,7 +293,8 @@ def test_merge_dispatch_table():
     assert _describe(7, C=1)[1] == "merge_u8_val3<N=7,U=4,PF=1,MAP=3,C=1>"                  # monochrome val-only: the bench kernel with one table column
     assert _describe(7, C=1, flat=True)[1] == "merge_u8_val3<N=7,U=2,PF=1,MAP=3,flat=1,C=1>"
     assert _describe(7, C=1, std=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0,C=1>"
-    assert _describe(7, C=1, std=True, flat=True)[1] == "merge_u8_loop_std<C=1,flat=1,sum_w=0>(N=7)"
+    assert _describe(7, C=1, std=True, flat=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=1,sum_w=0,C=1>"
+    assert _describe(7, C=1, std=True, sumw=True)[1] == "merge_u8_loop_std<C=1,flat=0,sum_w=1>(N=7)"
     assert _describe(17, C=1)[1] == "merge_u8_loop<C=1,flat=0,sum_w=0>(N=17)" and _describe(7, C=2)[1] == "merge_u8_loop<C=2,flat=0,sum_w=0>(N=7)"
     assert _describe(7, f64=True, std=True)[1] == "merge_f64_std<C=3,flat=0,sum_w=0>(N=7)"
     assert _describe(7, align=1)[1] == "merge_generic<f64in=0,std=0>"
