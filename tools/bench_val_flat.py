@@ -6,7 +6,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from camera_linearity_amd import engine  # noqa: E402
 from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark  # noqa: E402
 dev = torch.device("cuda:0")
-n, H, W = 7, 4096, 4096
+import os
+n, H, W = int(os.environ.get("BN", 7)), int(os.environ.get("BH", 4096)), int(os.environ.get("BW", 4096))
 icrf, diff = synthetic_icrf()
 frames, _, t = synthetic_stack_device(7, n, H, W, device=dev)
 flat, flat_std, dark = synthetic_flat_dark(7, H, W, device=dev)
