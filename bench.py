@@ -199,8 +199,8 @@ def row_tile_workload(a, dev, rank, world, dist):
     are dealt to the ranks (rank r merges tiles r, r + N, ...; N = 1 merges all 8 back to back), each tile is one fused
     launch on that rank's GPU, no data-path collective. A step = every rank merges all its tiles once; value = whole-image
     Mpix per second (total work is fixed: "strong" scaling). After the timed region the image is assembled ONCE on rank 0
-    (pinned buffers, asynchronous D2H on a side stream, tensor send / receive over a gloo group) - reported as
-    `assembly_ms`, never part of `value`."""
+    (one image in POSIX shared memory that every rank page-locks and copies its tiles into with asynchronous D2H copies on a
+    side stream; the gloo group carries a name and a barrier, no pixels) - reported as `assembly_ms`, never part of `value`."""
     from camera_linearity_amd import parallel
     from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf
     n, H, W, n_tiles = 15, 8192, 8192, 8
@@ -240,7 +240,9 @@ def row_tile_workload(a, dev, rank, world, dist):
     avg_us = ev0.elapsed_time(ev1) * 1e3 / a.steps / max(n_launch, 1)
     elapsed, ranks = rank_report(dist, a, dev, elapsed, avg_us)
     # host-side assembly of the image (once, untimed for `value`)
-    gloo = dist.new_group(backend="gloo") if (dist is not None and world > 1) else None
+    # the CPU group of the assembly (segment name, shape agreement, barrier): a gloo group inside the nccl world - also at world
+    # size 1 under --force-dist, so that this combination runs on a one-GPU box
+    gloo = dist.new_group(backend="gloo") if dist is not None else None
     barrier()
     ta = time.perf_counter()
     val, std = tiles.assemble(group=gloo, dst=0)        # the first call also page-locks the 1.6 GB (3.2 GB with std) image buffer
@@ -287,10 +289,12 @@ def row_tile_workload(a, dev, rank, world, dist):
                              "algorithmic_bytes_per_launch": alg // n_launch, "avg_launch_us": round(avg_us, 2)},
                 "ranks": ranks,
                 "assembly_ms": round(assembly_ms, 1), "assembly_first_ms": round(assembly_first_ms, 1),
-                "assembly": f"{n_tiles} tiles -> pinned host buffers (async D2H on a side stream) -> one {H}x{W}x3 float64 image"
-                            + (" (+ std)" if with_std else "") + " on rank 0",
+                "assembly": f"{n_tiles} tiles -> async D2H on a side stream into their rows of one {H}x{W}x3 float64 image"
+                            + (" (+ std)" if with_std else "") + f" on rank 0 [{tiles.assembly_path}]",
                 "cpu_baseline": cpu}
         print(json.dumps(line))
+    del val, std
+    tiles.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -539,6 +543,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if a.share_device:
         local_rank = 0
+    have = torch.cuda.device_count()
+    if have <= local_rank or (not a.share_device and have < world):
+        # one clear line per rank (every rank of the run exits, none waits in a rendezvous) instead of a set_device traceback
+        print(f"bench.py: rank {rank}: --gpus {a.gpus} needs GPU {local_rank} of {world} but this node shows {have} GPU(s) "
+              "(--share-device puts every rank on GPU 0: rehearsal only)", file=sys.stderr, flush=True)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

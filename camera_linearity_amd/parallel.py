@@ -10,10 +10,16 @@ merges its own units and results are assembled host-side. Two shardings:
                   flat-field ROI means are global scalars, computed once and passed by value.
   * whole stacks - a batch of independent stacks dealt round-robin to the ranks.
 
-The only inter-process traffic is the optional result gather over the CPU (gloo) group.
+Result assembly is host-side: the ranks of a node map ONE image in POSIX shared memory (SharedHostImage), page-lock it
+and copy their tiles from the device straight into their rows of it; the CPU (gloo) group carries the segment's name, a
+6-number shape agreement and a barrier - no pixel travels through it. (gather_tiles, tensor sends over the CPU group, stays as
+the fallback for when /dev/shm cannot hold the image, and for tiles that are host arrays already.)
 """
 from __future__ import annotations
 
+import mmap
+import os
+import secrets
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -93,12 +99,106 @@ def merge_row_tile(frames_host: Sequence[np.ndarray], exposures, icrf, icrf_diff
     return r0, r1, h_val.numpy(), (None if h_std is None else h_std.numpy())
 
 
+class SharedHostImage:
+    """ONE (H, W, C) float64 image - and optionally a second one for std - in POSIX shared memory (/dev/shm), mapped by every
+    rank of the node. Rank `dst` creates the segment, the others attach to it by name; every rank page-locks its mapping
+    (hipHostRegister through torch's cudart binding) so that its D2H copies land in the image directly and asynchronously, with
+    no staging buffer and no inter-process send. Construction is COLLECTIVE over `group` (a CPU / gloo group, or the default
+    group): the name travels by broadcast_object_list and a MIN-reduce agrees that every rank mapped it - if any rank could not
+    (no /dev/shm, not enough room in it), open() returns None on ALL ranks and the caller falls back to gather_tiles. The
+    creator unlinks the name as soon as everyone is attached, so nothing is left in /dev/shm if a rank dies later (the pages
+    live until the last mapping goes)."""
+
+    DIR = "/dev/shm"
+
+    def __init__(self, mm, shape, with_std: bool, name: str, owner: bool):
+        self._mm, self.shape, self.name, self.owner = mm, tuple(shape), name, owner
+        n = int(np.prod(shape, dtype=np.int64))
+        self.val = torch.frombuffer(mm, dtype=torch.float64, count=n, offset=0).reshape(self.shape)
+        self.std = torch.frombuffer(mm, dtype=torch.float64, count=n, offset=8 * n).reshape(self.shape) if with_std else None
+        self.nbytes = 8 * n * (2 if with_std else 1)
+        self.pinned = False
+
+    @staticmethod
+    def _map(path: str, nbytes: int, create: bool):
+        fd = os.open(path, os.O_RDWR | (os.O_CREAT | os.O_EXCL if create else 0), 0o600)
+        try:
+            if create:
+                os.posix_fallocate(fd, 0, nbytes)           # ENOSPC here, not a SIGBUS at the first touch of a page tmpfs cannot back
+            return mmap.mmap(fd, nbytes)
+        except BaseException:
+            if create:
+                os.unlink(path)
+            raise
+        finally:
+            os.close(fd)
+
+    @classmethod
+    def open(cls, shape, with_std: bool, group=None, rank: int = 0, dst: int = 0, world_size: int = 1) -> Optional["SharedHostImage"]:
+        import torch.distributed as dist
+        nbytes = 8 * int(np.prod(shape, dtype=np.int64)) * (2 if with_std else 1)
+        collective = world_size > 1 or (group is not None)
+        name, mm = None, None
+        if rank == dst and nbytes > 0:
+            name = f"hm_image_{os.getpid()}_{secrets.token_hex(6)}"
+            try:
+                mm = cls._map(os.path.join(cls.DIR, name), nbytes, create=True)
+            except OSError:
+                name, mm = None, None
+        if collective:
+            box = [name]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+            name = box[0]
+            if rank != dst and name is not None:
+                try:
+                    mm = cls._map(os.path.join(cls.DIR, name), nbytes, create=False)
+                except OSError:
+                    mm = None
+            ok = torch.tensor([1 if mm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)               # also the "everyone is attached" barrier
+            all_ok = bool(ok.item())
+        else:
+            all_ok = mm is not None
+        if rank == dst and name is not None:
+            try:
+                os.unlink(os.path.join(cls.DIR, name))
+            except OSError:
+                pass
+        if not all_ok:
+            if mm is not None:
+                mm.close()
+            return None
+        return cls(mm, shape, with_std, name, rank == dst)
+
+    def pin(self) -> bool:
+        """Page-lock this process's mapping for the GPU (every rank pins its own mapping). False = the runtime refused: copies into
+        the image still work, synchronously through the runtime's own staging."""
+        if self.pinned or not torch.cuda.is_available():
+            return self.pinned
+        rc = torch.cuda.cudart().cudaHostRegister(self.val.data_ptr(), self.nbytes, 0)
+        self.pinned = int(rc) == 0
+        return self.pinned
+
+    def close(self) -> None:
+        if self._mm is None:
+            return
+        if self.pinned:
+            torch.cuda.cudart().cudaHostUnregister(self.val.data_ptr())
+            self.pinned = False
+        self.val = self.std = None
+        try:
+            self._mm.close()
+        except BufferError:          # a caller still holds a view of the image: the mapping goes when that view does
+            pass
+        self._mm = None
+
+
 class RowTileSet:
     """The row tiles of ONE large image that this rank owns, resident on its GPU (config 4: a 15 x 8192 x 8192 x 3
     stack cut into 8 tiles of 1024 rows). `launch()` enqueues one fused merge per tile; `download()` brings the results
     back through pinned buffers with asynchronous D2H copies on a side stream (tile k's copy overlaps tile k+1's);
-    `assemble()` concatenates the tiles of all ranks on `dst` through the CPU (gloo) group with tensor gathers into a
-    preallocated image - no pickling, no per-tile temporaries. There is no GPU<->GPU traffic on this path."""
+    `assemble()` puts the tiles of all ranks into ONE host image on `dst`: a shared-memory image every rank copies its own rows
+    into (SharedHostImage), or - fallback - tensor sends over the CPU (gloo) group. There is no GPU<->GPU traffic on this path."""
 
     def __init__(self, height: int, n_tiles: int, rank: int = 0, world_size: int = 1, median_k: int = 0):
         self.height, self.n_tiles, self.rank, self.world = height, n_tiles, rank, world_size
@@ -108,6 +208,7 @@ class RowTileSet:
         self.plans = {}
         self._host = {}
         self._copy_stream = None
+        self.assembly_path = None
 
     def input_rows(self, tile: int) -> Tuple[int, int]:
         r0, r1 = self.bounds[tile]
@@ -164,11 +265,49 @@ class RowTileSet:
         side.synchronize()
         return out
 
-    def assemble(self, group=None, dst: int = 0, copy: bool = False):
-        """(val, std) of the whole image as host tensors on `dst`, (None, None) elsewhere. The destination rank's own tiles go from the
-        device straight into their rows of the (pinned) image; the other ranks' tiles arrive over the CPU group into theirs.
-        The returned tensors ARE this object's pinned image buffers: the next assemble() (the next stack of a loop) overwrites them.
-        copy=True returns tensors of the caller's own instead (one more host copy of the image)."""
+    def _agree_shape(self, group):
+        """(W, C, with_std) of the image, the same on every rank (ranks that own no tile learn it from the others)."""
+        import torch.distributed as dist
+        meta = torch.zeros(3, dtype=torch.int64)
+        if self.mine:
+            o = self.plans[self.mine[0]].outputs
+            meta[0], meta[1], meta[2] = o["val"].shape[1], o["val"].shape[2], int("std" in o)
+        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+        return int(meta[0]), int(meta[1]), bool(meta[2])
+
+    def assemble(self, group=None, dst: int = 0, copy: bool = False, shared: bool = True):
+        """(val, std) of the whole image as host tensors on `dst`, (None, None) elsewhere.
+        One rank and no group: the tiles go from the device straight into their rows of a pinned image of this object's.
+        Several ranks (or a group): the image lives in POSIX shared memory that every rank maps and page-locks
+        (SharedHostImage); every rank copies its tiles from its GPU straight into its rows of it and a barrier on the CPU group
+        says "all rows are there" - nothing is sent between processes. shared=False, or a /dev/shm that cannot hold the image,
+        selects the older path: per-tile tensor sends over the CPU group into dst's pinned image (gather_tiles).
+        `self.assembly_path` names the path the last call took. The returned tensors ARE this object's image buffers: the next
+        assemble() (the next stack of a loop) overwrites them. copy=True returns tensors of the caller's own instead."""
+        collective = self.world > 1 or group is not None
+        if collective and shared:
+            import torch.distributed as dist
+            W, Cc, with_std = self._agree_shape(group)
+            key = (self.height, W, Cc, with_std)
+            if getattr(self, "_shared_key", None) != key:
+                if getattr(self, "_shared", None) is not None:
+                    self._shared.close()
+                self._shared = SharedHostImage.open((self.height, W, Cc), with_std, group=group, rank=self.rank, dst=dst,
+                                                    world_size=self.world)
+                self._shared_key = key
+                if self._shared is not None:
+                    self._shared.pin()
+            img = self._shared
+            if img is not None:
+                self.download(into=(img.val, img.std))
+                dist.barrier(group=group)                  # every rank's rows have landed
+                self.assembly_path = "shared-memory image" + ("" if img.pinned else " (not page-locked)")
+                if self.rank != dst:
+                    return None, None
+                val, std = img.val, img.std
+                if copy:
+                    val, std = val.clone(), (None if std is None else std.clone())
+                return val, std
         image = None
         if self.rank == dst and self.mine:
             o = self.plans[self.mine[0]].outputs
@@ -180,10 +319,16 @@ class RowTileSet:
                 self._image_key = key
             image = self._image
         local = self.download(into=image)
+        self.assembly_path = "pinned image" if not collective else "tensor sends over the CPU group"
         val, std = gather_tiles(local, self.bounds, group=group, dst=dst, world_size=self.world, rank=self.rank, image=image)
         if copy and val is not None:
             val, std = val.clone(), (None if std is None else std.clone())
         return val, std
+
+    def close(self) -> None:
+        if getattr(self, "_shared", None) is not None:
+            self._shared.close()
+            self._shared, self._shared_key = None, None
 
 
 def gather_tiles(local: dict, bounds: Sequence[Tuple[int, int]], group=None, dst: int = 0, world_size: int = 1, rank: int = 0, image=None):

@@ -334,7 +334,8 @@ def case_ramp():
 
 
 def case_float():
-    """(v) float64 input: .5 ties of v*255 (half-to-even), values off the k/255 grid, >1.0 wrap, tiny negatives."""
+    """(v) float64 input: .5 ties of v*255 (half-to-even), values off the k/255 grid, >1.0 wrap, and NEGATIVE values in [-3/255, 0)
+    (bias-subtracted frames, modules/image_set.py:520,538): around() then astype(uint8) wraps them to 253..255 (modules/measurand.py:503,531)."""
     rng = np.random.default_rng(4)
     h, w = 8, 24
     v = rng.random((3, h, w, 3))
@@ -344,10 +345,16 @@ def case_float():
     v[2].reshape(-1)[:16] = np.arange(16) / 255                           # exact grid values
     v[2].reshape(-1)[16:24] = 1.0
     v[2].reshape(-1)[24:32] = 0.0
+    # negatives (no further rng draws, so every other entry of the fixture keeps its value): -0.25/255 .. -3/255 in steps of 0.25/255 - this
+    # holds the ties -0.5/255 (-> -0 -> 0), -1.5/255 and -2.5/255 (-> -2 -> 254) - plus -1e-9, -0.0 and the exact -1/255, -2/255, -3/255
+    v[1].reshape(-1)[40:52] = -np.arange(1, 13) * 0.25 / 255
+    v[1].reshape(-1)[52:57] = [-1e-9, -0.0, -1 / 255, -2 / 255, -3 / 255]
+    v[0].reshape(-1)[80:84] = [-0.5 / 255, -1.5 / 255, -2.5 / 255, -2.9 / 255]
     t = np.array([0.002, 0.004, 0.008])
     icrf, diff = make_icrf((2.2, 2.0, 1.8))
     stds = [0.01 * (1 + rng.random((h, w, 3))) for _ in range(3)]
     out = merge([v[i] for i in range(3)], stds, t, icrf, diff)
+    assert v.min() < -2.9 / 255 and set(np.unique(out["idx"][1].reshape(-1)[40:57])) >= {0, 253, 254, 255}
     m = Measurand(v[0].copy(), stds[0].copy())
     wgt, dwgt = m.apply_gaussian_weight()
     lin_val, lin_std = ref_linearize(m, icrf, diff)

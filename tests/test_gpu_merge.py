@@ -127,6 +127,34 @@ def test_linearize_index_bit_exact_and_values(eng, golden):
         assert np.array_equal(host(idx), g["idx"][i])
 
 
+def test_negative_float_inputs_wrap_like_numpy(eng, golden):
+    """Bias-subtracted frames can be negative (modules/image_set.py:520,538): around(v * 255).astype(uint8) wraps them to 253..255
+    (modules/measurand.py:503,531). The reference-generated fixture pins -0.25/255 .. -3/255 incl. the -0.5 / -1.5 / -2.5 ties, -1e-9 and
+    -0.0; a larger frame (burst kernel + ragged rest) is held to NumPy's own cast of the same expression. Bit-exact."""
+    g = golden("merge_float")
+    v = g["frames_f64"]
+    assert v.min() <= -3 / 255 and (v < 0).sum() >= 20
+    neg = v[1] < 0
+    _, _, idx = eng.linearize(dev(v[1]), None, g["icrf"], return_index=True)
+    assert np.array_equal(host(idx)[neg], g["idx"][1][neg]) and set(np.unique(g["idx"][1][neg])) == {0, 253, 254, 255}
+    rng = np.random.default_rng(12)
+    big = rng.uniform(-0.02, 1.02, size=(67, 113, 3))
+    big.reshape(-1)[:9] = [-0.5 / 255, -1.5 / 255, -2.5 / 255, -3.5 / 255, -0.0, 255.5 / 255, 256.5 / 255, -1 / 255, -4.0]
+    want = np.around(big * 255).astype(np.uint8)                                  # measurand.py:503
+    val, _, idx = eng.linearize(dev(big), None, g["icrf"], return_index=True)
+    assert np.array_equal(host(idx), want)
+    assert np.array_equal(host(val), np.take_along_axis(g["icrf"], want.reshape(-1, 3).astype(np.int64), axis=0).reshape(big.shape))
+    # the float64 merge kernels compute the same index: a two-frame stack of the negative-bearing frame against the oracle
+    fr = [big, np.clip(big * 2, -0.01, 1.0)]
+    sd = [np.full(big.shape, 0.01), np.full(big.shape, 0.02)]
+    ref = orc.merge(fr, [0.001, 0.002], g["icrf"], g["icrf_diff"], stds=sd)
+    out = eng.merge([dev(f) for f in fr], [0.001, 0.002], g["icrf"], g["icrf_diff"], [dev(s_) for s_ in sd])
+    close(host(out["val"]), ref["val"], F64_RTOL)
+    close(host(out["std"]), ref["std"], STD_RTOL)
+    out = eng.merge([dev(f) for f in fr], [0.001, 0.002], g["icrf"])
+    close(host(out["val"]), ref["val"], F64_RTOL)
+
+
 def test_linearize_u8_and_single_channel_lut(eng, golden):
     g = golden("merge_std")
     f = g["frames"][1]

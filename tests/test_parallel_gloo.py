@@ -125,3 +125,79 @@ def test_gather_tiles_single_rank():
     local = {t: (torch.as_tensor(img[r0:r1].copy()), None) for t, (r0, r1) in enumerate(bounds)}
     val, std = parallel.gather_tiles(local, bounds)
     assert std is None and np.array_equal(val.numpy(), img)
+
+
+def _worker_shared(rank, world, port, q, shm_dir):
+    """The shared-memory assembly of RowTileSet.assemble without a GPU: every rank writes its tiles' rows straight into the one
+    image (here with a host copy where the product issues a D2H copy); the group carries a name, a flag and a barrier."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_linearity_amd import parallel
+    if shm_dir is not None:
+        parallel.SharedHostImage.DIR = shm_dir
+    rng = np.random.default_rng(5)
+    H, W, n_tiles = 37, 6, 5
+    img = rng.random((H, W, 3))
+    sd = rng.random((H, W, 3))
+    bounds = parallel.row_tile_bounds(H, n_tiles)
+    shared = parallel.SharedHostImage.open((H, W, 3), True, group=None, rank=rank, dst=0, world_size=world)
+    if shared is None:
+        q.put(("fallback", rank))
+    else:
+        assert not shared.pin()                       # no GPU here: nothing to page-lock for, and nothing raised
+        for t in parallel.tiles_for_rank(n_tiles, rank, world):
+            r0, r1 = bounds[t]
+            shared.val[r0:r1].copy_(torch.as_tensor(img[r0:r1]))
+            shared.std[r0:r1].copy_(torch.as_tensor(sd[r0:r1]))
+        dist.barrier()
+        if rank == 0:
+            left = [f for f in os.listdir(parallel.SharedHostImage.DIR) if f == shared.name]
+            q.put((shared.val.numpy().copy(), shared.std.numpy().copy(), left))
+        dist.barrier()
+        shared.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shared_host_image_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shared, args=(r, world, port, q, None)) for r in range(world)]
+    for p in procs:
+        p.start()
+    val, std, left = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    assert np.array_equal(val, rng.random((37, 6, 3)))
+    assert np.array_equal(std, rng.random((37, 6, 3)))
+    assert left == []                                  # the name is unlinked as soon as every rank is attached
+
+
+def test_shared_host_image_falls_back_on_every_rank(tmp_path):
+    """No usable shared-memory directory on the creating rank: open() returns None on EVERY rank (the caller then takes gather_tiles)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shared, args=(r, 2, port, q, str(tmp_path / "absent"))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [("fallback", 0), ("fallback", 1)]
+
+
+def test_shared_host_image_single_process():
+    from camera_linearity_amd import parallel
+    s = parallel.SharedHostImage.open((4, 3, 3), False)
+    assert s is not None and s.std is None and s.val.shape == (4, 3, 3)
+    s.val.fill_(2.5)
+    assert float(s.val.sum()) == 90.0
+    assert not os.path.exists(os.path.join(parallel.SharedHostImage.DIR, s.name))
+    s.close()
+    s.close()
