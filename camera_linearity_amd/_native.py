@@ -44,6 +44,7 @@ class MergeArgs(C.Structure):
         ("ff_mean", C.c_double * HM_MAX_CHANNELS), ("ff_std_mean", C.c_double * HM_MAX_CHANNELS),
         ("out_val", C.c_void_p), ("out_std", C.c_void_p), ("out_sum_w", C.c_void_p),
         ("hot_workspace", C.c_void_p), ("hot_workspace_bytes", C.c_size_t),
+        ("frames_workspace", C.c_void_p), ("frames_workspace_bytes", C.c_size_t),
     ]
 
 
@@ -63,6 +64,7 @@ _SIGNATURES = {
     "hm_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
     "hm_merge_hot_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "hm_merge_hot_workspace_min_bytes": (C.c_size_t, [C.c_int64]),
+    "hm_merge_frames_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
     "hm_merge_algorithmic_bytes": (C.c_int64, [C.POINTER(MergeArgs)]),
     "hm_merge_describe": (C.c_int, [C.POINTER(MergeArgs), C.c_char_p, C.c_int]),
     "hm_hot_pixel_filter_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
@@ -96,6 +98,12 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "hm_channel_statistics_workspace_bytes": (C.c_size_t, []),
     "hm_channel_statistics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hm_axis_statistics_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "hm_axis_statistics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hm_compute_difference_bcast": (C.c_int, [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 4 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                                                              C.POINTER(C.c_int64), C.c_void_p]),
+    "hm_interpolate_bcast": (C.c_int, [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                                             C.POINTER(C.c_int64), C.c_void_p]),
     "hm_welford_update": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_int, C.c_void_p]),
     "hm_welford_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -145,8 +153,9 @@ def _load():
 
 
 lib = _load()
-if lib.hm_version() != 1:
-    raise ImportError(f"libhdrmerge ABI version {lib.hm_version()} != 1 expected by this package")
+HM_ABI_VERSION = 2
+if lib.hm_version() != HM_ABI_VERSION:
+    raise ImportError(f"libhdrmerge ABI version {lib.hm_version()} != {HM_ABI_VERSION} expected by this package")
 
 
 def strerror(code: int) -> str:

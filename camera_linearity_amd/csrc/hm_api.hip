@@ -10,7 +10,7 @@ extern "C" const char* hm_strerror(int code) {
     switch (code) {
         case HM_OK: return "ok";
         case HM_EINVAL: return "invalid argument";
-        case HM_EUNSUPPORTED: return "unsupported configuration (frames > HM_MAX_FRAMES or channels > HM_MAX_CHANNELS)";
+        case HM_EUNSUPPORTED: return "unsupported configuration (channels > HM_MAX_CHANNELS, or frames > HM_MAX_FRAMES without frames_workspace / out_sum_w)";
         case HM_EALIGN: return "float64 buffer is not 8-byte aligned";
         case HM_ELAUNCH: return "HIP kernel launch failed";
         case HM_ENODEVICE: return "no usable gfx950 device";

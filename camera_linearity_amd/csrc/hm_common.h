@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hdrmerge.h"
+#include <string>
 
 namespace hm {
 
@@ -22,6 +23,9 @@ __device__ __forceinline__ bool aligned_dev(const void* p, size_t a) { return (r
 
 // number of CUs of the current device (cached)
 int cu_count();
+
+// hm_merge_chunk.hip: stacks of more than HM_MAX_FRAMES frames, HM_MAX_FRAMES (or chunk_frames) per launch
+int merge_chunked(const hm_merge_args* g, int chunk_frames, std::string* describe, hipStream_t st);
 
 // grid for a bandwidth-bound grid-stride kernel: enough blocks to fill the chip, capped (guide G11)
 inline unsigned stream_grid(int64_t work_items, int block, int blocks_per_cu) {
@@ -48,6 +52,22 @@ __device__ __forceinline__ double gauss_weight(double dv) { return 1.0 + -30.0 *
 #else
 __device__ __forceinline__ double gauss_weight(double dv) { return exp(-30.0 * (dv * dv)); }
 #endif
+
+// flat-field epilogue on loaded operands, modules/measurand.py:585-602. The value keeps the reference's
+// operations, (val / F) * m (:602). The three variance terms (:586-596) each divide by F**2 or F**4 in the
+// reference; here 1/F**2 is formed once and multiplied (3 float64 divisions fewer per element; the std
+// moves by <= 2 ulp, its test tolerance is 1e-9).
+__device__ __forceinline__ void flat_field_math(double F, double iF2 /* 1 / (F*F) */, double sF, double m, double s,
+                                                bool with_std, double& val, double& sd) {
+    if (with_std) {
+        const double v2 = val * val;
+        const double u_acq = ((sd * sd) * iF2) * (m * m);
+        const double u_ff = ((v2 * (iF2 * iF2)) * (sF * sF)) * (m * m);
+        const double u_ffm = (v2 * iF2) * (s * s);
+        sd = sqrt(u_acq + u_ff + u_ffm);
+    }
+    val = (val / F) * m;
+}
 
 // scipy.ndimage 'reflect' (d c b a | a b c d) index fold, valid for any offset
 __device__ __forceinline__ int64_t reflect_index(int64_t i, int64_t n) {

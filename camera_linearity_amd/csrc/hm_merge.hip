@@ -26,6 +26,7 @@
 #include "hm_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <type_traits>
 
@@ -77,22 +78,6 @@ __device__ __forceinline__ void elem_to_pixel(const MergeK& a, int64_t e, int64_
     const int64_t rem = e % wc;
     col = rem / a.C;
     c = static_cast<int>(rem % a.C);
-}
-
-// flat-field epilogue on loaded operands, modules/measurand.py:585-602. The value keeps the reference's
-// operations, (val / F) * m (:602). The three variance terms (:586-596) each divide by F**2 or F**4 in the
-// reference; here 1/F**2 is formed once and multiplied (3 float64 divisions fewer per element; the std
-// moves by <= 2 ulp, its test tolerance is 1e-9).
-__device__ __forceinline__ void flat_field_math(double F, double iF2 /* 1 / (F*F) */, double sF, double m, double s,
-                                                bool with_std, double& val, double& sd) {
-    if (with_std) {
-        const double v2 = val * val;
-        const double u_acq = ((sd * sd) * iF2) * (m * m);
-        const double u_ff = ((v2 * (iF2 * iF2)) * (sF * sF)) * (m * m);
-        const double u_ffm = (v2 * iF2) * (s * s);
-        sd = sqrt(u_acq + u_ff + u_ffm);
-    }
-    val = (val / F) * m;
 }
 
 __device__ __forceinline__ void flat_field_apply(const MergeK& a, int64_t e, int c, bool with_std,
@@ -1306,6 +1291,14 @@ __device__ __forceinline__ bool entry_inrange(double w, double wg) {
 // the table offsets. Before, a flat field sent the val-only merge to merge_u8_fast (186 us / 0.54 on config 2's stack).
 // CH (round 3): 3 = colour (the channel pattern above), 1 = monochrome cameras - one table column, no channel bookkeeping at all; before,
 // every C != 3 stack went to the run-time-N, run-time-C merge_u8_loop (0.62-0.68 val-only on 7 x 4096 x 4096 x 1).
+#ifndef HM_VAL3_PROBE
+#define HM_VAL3_PROBE 0      // measurement builds only (wrong results): 1 = no LDS gathers (the ceiling of the HBM access pattern); 2 = every unit's
+#endif                       // frame bytes come from the first 64 units (L2 hits; the gathers and the stores are real); 3 = 2 without the stores
+#if HM_VAL3_PROBE >= 2
+#define HM_PROBE_UNIT(x) ((x) & 63u)
+#else
+#define HM_PROBE_UNIT(x) (x)
+#endif
 template <int NF, int U, int PF, int MAP, bool FLAT = false, int CH = 3>
 __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     static_assert(CH == 3 || CH == 1, "colour or monochrome");
@@ -1347,9 +1340,9 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
             if constexpr (PF == 0) {
                 const __amdgpu_buffer_rsrc_t fr = frame_rsrc(static_cast<const uint8_t*>(a.frame[i]) + a.in_off);
 #pragma unroll
-                for (int s = 0; s < U; ++s) dst[i][s] = ld_u16_buf(fr, lane2 + SLOT * s, unit * UNIT);
+                for (int s = 0; s < U; ++s) dst[i][s] = ld_u16_buf(fr, lane2 + SLOT * s, HM_PROBE_UNIT(unit) * UNIT);
             } else {
-                const uint8_t* p = static_cast<const uint8_t*>(a.frame[i]) + a.in_off + static_cast<int64_t>(unit) * UNIT;
+                const uint8_t* p = static_cast<const uint8_t*>(a.frame[i]) + a.in_off + static_cast<int64_t>(HM_PROBE_UNIT(unit)) * UNIT;
 #pragma unroll
                 for (int s = 0; s < U; ++s) dst[i][s] = ld_u16(p + SLOT * s + lane2);
             }
@@ -1396,7 +1389,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
     // one unit out of `cur`; REFILL (PF == 0 only): fetch the next unit's bytes into the registers this one frees
     auto process = [&](auto refill_tag, uint32_t unit, auto& cur) {
         constexpr bool REFILL = decltype(refill_tag)::value;
-        const uint32_t next_off = (unit + ustride) * UNIT;                                   // scalar: byte offset of the next unit in every frame
+        const uint32_t next_off = HM_PROBE_UNIT(unit + ustride) * UNIT;                                   // scalar: byte offset of the next unit in every frame
         double* og = a.out_val + static_cast<int64_t>(unit) * UNIT + wave_el;                // scalar base of the wave's output in this unit
         double held[DEFER ? U : 1][2];
         if constexpr (PIPE) {
@@ -1485,7 +1478,11 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
                         const double it = a.inv_t[i0 + f];
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
+#if HM_VAL3_PROBE == 1
+                            const double2 t = double2{static_cast<double>(addr[f][j] + 1u), static_cast<double>(addr[f][j])};
+#else
                             const double2 t = *reinterpret_cast<const double2*>(lds + addr[f][j]);
+#endif
                             if (i0 + f == 0) { S[j] = t.x; acc[j] = t.y * it; }
                             else {
                                 S[j] += t.x;                               // exposure_series.py:340
@@ -1503,7 +1500,11 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
             else { v0 = acc[0] / S[0]; v1 = acc[1] / S[1]; }
             flat_epilogue(s, cur[NS - 1][s], v0, v1);
             if constexpr (DEFER) { held[s][0] = v0; held[s][1] = v1; }
+#if HM_VAL3_PROBE == 3
+            else { if (v0 != v0 && v1 == 12345.0) store2(og + SLOT * s, lane16, v0, v1); }
+#else
             else store2(og + SLOT * s, lane16, v0, v1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DEFER) {                      // U KB of contiguous output in U back-to-back store instructions
@@ -2429,12 +2430,26 @@ extern "C" int hm_merge_describe(const hm_merge_args* g, char* buf, int buf_len)
     return rc;
 }
 
-extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
+// struct_size values hm_merge accepts: the current layout and the two older ones of ABI version 1 (without the hot-pixel queue
+// workspace: 264 bytes; with it: 280 bytes) - the missing tail reads as zero (no workspace).
+static bool widen_args(const hm_merge_args* g, hm_merge_args& full) {
+    if (!g) return false;
+    const uint32_t sz = g->struct_size;
+    if (sz != sizeof(hm_merge_args) && sz != 264u && sz != 280u) return false;
+    full = hm_merge_args{};
+    memcpy(&full, g, sz < sizeof(hm_merge_args) ? sz : sizeof(hm_merge_args));
+    full.struct_size = sizeof(hm_merge_args);
+    return true;
+}
+
+extern "C" int hm_merge(const hm_merge_args* g_in, void* stream) {
     using namespace hm;
-    if (!g || g->struct_size != sizeof(hm_merge_args)) return HM_EINVAL;
+    hm_merge_args full;
+    if (!widen_args(g_in, full)) return HM_EINVAL;
+    const hm_merge_args* g = &full;
     const int N = g->n_frames, C = g->channels;
     if (N < 1 || C < 1 || g->height < 1 || g->width < 1 || g->rows < 0) return HM_EINVAL;
-    if (N > HM_MAX_FRAMES || C > HM_MAX_CHANNELS) return HM_EUNSUPPORTED;
+    if (C > HM_MAX_CHANNELS) return HM_EUNSUPPORTED;
     if (g->rows == 0) return g->row0 >= 0 && g->row0 <= g->height ? HM_OK : HM_ESHAPE;   // empty tile: nothing to do
     const bool f64in = g->frames_f64 != nullptr;
     if (f64in == (g->frames_u8 != nullptr)) return HM_EINVAL;          // exactly one input kind
@@ -2466,6 +2481,27 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
         const int64_t need_hi = g->row0 + g->rows + r > g->height ? g->height : g->row0 + g->rows + r;
         if (g->buf_row0 > need_lo || g->buf_row0 + g->buf_rows < need_hi) return HM_ESHAPE;   // halo too small
     }
+    // per-frame pointers and exposures (any N: the chunked path below has no frame limit)
+    for (int i = 0; i < N; ++i) {
+        const void* f = f64in ? static_cast<const void*>(g->frames_f64[i]) : static_cast<const void*>(g->frames_u8[i]);
+        if (!f) return HM_EINVAL;
+        if (f64in && !aligned(f, 8)) return HM_EALIGN;
+        if (with_std) {
+            if (!g->stds[i]) return HM_EINVAL;
+            if (!aligned(g->stds[i], 8)) return HM_EALIGN;
+        }
+        if (!(g->exposures[i] > 0.0)) return HM_EINVAL;
+    }
+    if ((g->out_val && !aligned(g->out_val, 8)) || (g->out_std && !aligned(g->out_std, 8)) ||
+        (g->out_sum_w && !aligned(g->out_sum_w, 8))) return HM_EALIGN;
+    // More frames than one launch takes (modules/exposure_series.py:334,372 have no limit): HM_MAX_FRAMES per launch with the running
+    // sums in memory (hm_merge_chunk.hip). variant <= -2 forces that path with -variant frames per chunk (tests: any chunking gives the
+    // bits of the one-launch kernels).
+    if (N > HM_MAX_FRAMES || g->variant <= -2) {
+        int chunk = g->variant <= -2 ? -g->variant : HM_MAX_FRAMES;
+        if (chunk > HM_MAX_FRAMES) chunk = HM_MAX_FRAMES;
+        return merge_chunked(g, chunk, g_describe, as_stream(stream));
+    }
     // The streaming kernels index groups and buffer offsets with 32 bits: a tile of 2^32 elements or more is merged as consecutive
     // row bands of fewer than 2^32 elements each (same buffers, row0 / rows / output pointers advanced; an even number of rows per band
     // keeps every band's first byte 2-byte aligned). Only a single row of >= 2^32 elements is left to merge_generic.
@@ -2494,16 +2530,8 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     }
     MergeK k{};
     for (int i = 0; i < N; ++i) {
-        const void* f = f64in ? static_cast<const void*>(g->frames_f64[i]) : static_cast<const void*>(g->frames_u8[i]);
-        if (!f) return HM_EINVAL;
-        if (f64in && !aligned(f, 8)) return HM_EALIGN;
-        k.frame[i] = f;
-        if (with_std) {
-            if (!g->stds[i]) return HM_EINVAL;
-            if (!aligned(g->stds[i], 8)) return HM_EALIGN;
-            k.sd[i] = g->stds[i];
-        }
-        if (!(g->exposures[i] > 0.0)) return HM_EINVAL;
+        k.frame[i] = f64in ? static_cast<const void*>(g->frames_f64[i]) : static_cast<const void*>(g->frames_u8[i]);
+        if (with_std) k.sd[i] = g->stds[i];
         k.inv_t[i] = 1.0 / g->exposures[i];
         k.dark[i] = hot ? g->darks_u8[i] : nullptr;
         k.dark_min[i] = hot && g->dark_min_dn ? g->dark_min_dn[i] : 256;
@@ -2512,8 +2540,6 @@ extern "C" int hm_merge(const hm_merge_args* g, void* stream) {
     k.flat_u8 = g->flat_u8; k.flat_f64 = g->flat_f64; k.flat_std = g->flat_std;
     for (int c = 0; c < HM_MAX_CHANNELS; ++c) { k.ff_mean[c] = g->ff_mean[c]; k.ff_std_mean[c] = g->ff_std_mean[c]; }
     k.out_val = g->out_val; k.out_std = g->out_std; k.out_sum_w = g->out_sum_w;
-    if ((k.out_val && !aligned(k.out_val, 8)) || (k.out_std && !aligned(k.out_std, 8)) ||
-        (k.out_sum_w && !aligned(k.out_sum_w, 8))) return HM_EALIGN;
     const int64_t E = g->rows * g->width * C;
     k.n_elems = E; k.elem0 = 0;
     k.in_off = (g->row0 - g->buf_row0) * g->width * C;

@@ -1321,3 +1321,243 @@ extern "C" int hm_channel_histogram(const double* val, const double* std, int64_
     hipLaunchKernelGGL(k_hist_final, dim3((nb + 255) / 256), dim3(256), 0, st, static_cast<const double*>(workspace), grid, nb, out);
     return launch_status();
 }
+
+// ================================================================================================
+// compute_dimension_statistics over ANY axis (modules/measurand.py:318-350 take a NumPy axis argument): the array is seen as a dense
+// (outer, A, inner) block and reduced over A - out[o, i] from x[(o A + k) inner + i], k = 0..A-1. (Reduced axes that are not adjacent
+// are brought together by the caller with a layout copy.) Same one-pass moments and NaN rules as the channel statistics above
+// (MomAcc / mom_merge / mom_finish). Two shapes:
+//   k_axis_thread   one thread per output (o, i): lanes run along i (contiguous) - inner >= 16, or short axes (A <= 32: e.g. the
+//                   channel axis of an image, where a lane reads its A consecutive values itself);
+//   k_axis_row      inner < 16 and a long axis: the A x inner values of one o are contiguous; a workgroup strides over them with a
+//                   thread count that is a multiple of inner (every thread keeps ONE channel), then folds threads of equal channel.
+// Both split A into KS segments (grid dimension) when there are too few outputs to fill the chip; k_axis_final folds the segments.
+// ================================================================================================
+namespace hm {
+
+__device__ __forceinline__ void axis_finish_store(const Mom& m, bool weighted, int64_t j, double* out_mean, double* out_std, double* out_err) {
+    double mean, sdv, err;
+    mom_finish(m, weighted, mean, sdv, err);
+    out_mean[j] = mean; out_std[j] = sdv;
+    if (out_err) out_err[j] = err;
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_axis_thread(const double* __restrict__ val, const double* __restrict__ sd, int64_t outer, int64_t A,
+                                                     int64_t inner, int KS, double* __restrict__ partial, double* __restrict__ out_mean,
+                                                     double* __restrict__ out_std, double* __restrict__ out_err) {
+    const int64_t n_out = outer * inner;
+    const int seg = blockIdx.y;
+    const int64_t jstride = static_cast<int64_t>(gridDim.x) * 256;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; j < n_out; j += jstride) {
+        const int64_t o = j / inner, i = j - o * inner;
+        const double* pv = val + (o * A) * inner + i;
+        const double* ps = WEIGHTED ? sd + (o * A) * inner + i : nullptr;
+        MomAcc st = acc_zero();
+        int it = 0;
+        for (int64_t k = seg; k < A; k += KS) {
+            const double v = pv[k * inner];
+            const double s = WEIGHTED ? ps[k * inner] : 1.0;
+            const double w = WEIGHTED ? 1.0 / s : 1.0;                          // measurand.py:342
+            acc_add(st, v, w, s, WEIGHTED, true);
+            if ((++it & (kMomBlock - 1)) == 0) acc_fold<false>(st);
+        }
+        const Mom m = acc_finish<false>(st, WEIGHTED);
+        if (KS == 1) axis_finish_store(m, WEIGHTED, j, out_mean, out_std, out_err);
+        else mom_store(partial + (static_cast<int64_t>(seg) * n_out + j) * kMomVals, m);
+    }
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_axis_row(const double* __restrict__ val, const double* __restrict__ sd, int64_t outer, int64_t A,
+                                                  int64_t inner, int KS, double* __restrict__ partial, double* __restrict__ out_mean,
+                                                  double* __restrict__ out_std, double* __restrict__ out_err) {
+    __shared__ double red[256][kMomVals];
+    const int in = static_cast<int>(inner);
+    const int Tm = (256 / in) * in;                                             // active threads: a multiple of inner
+    const int seg = blockIdx.x;
+    const int64_t seg_k = (A + KS - 1) / KS;                                    // axis positions per segment
+    const int64_t e_lo = static_cast<int64_t>(seg) * seg_k * inner;
+    int64_t e_hi = e_lo + seg_k * inner;
+    if (e_hi > A * inner) e_hi = A * inner;
+    const int64_t n_out = outer * inner;
+    for (int64_t o = blockIdx.y; o < outer; o += gridDim.y) {
+        MomAcc st = acc_zero();
+        if (static_cast<int>(threadIdx.x) < Tm) {
+            const double* pv = val + o * A * inner;
+            const double* ps = WEIGHTED ? sd + o * A * inner : nullptr;
+            int it = 0;
+            for (int64_t e = e_lo + threadIdx.x; e < e_hi; e += Tm) {
+                const double v = pv[e];
+                const double s = WEIGHTED ? ps[e] : 1.0;
+                const double w = WEIGHTED ? 1.0 / s : 1.0;
+                acc_add(st, v, w, s, WEIGHTED, true);
+                if ((++it & (kMomBlock - 1)) == 0) acc_fold<false>(st);
+            }
+        }
+        const Mom mine = acc_finish<false>(st, WEIGHTED);
+        __syncthreads();                                                        // (the previous o is done with `red`)
+        mom_store(red[threadIdx.x], mine);
+        __syncthreads();
+        if (static_cast<int>(threadIdx.x) < in) {                               // thread i folds the threads of channel i, in order
+            Mom m = mom_load(red[threadIdx.x]);
+            for (int t = threadIdx.x + in; t < Tm; t += in) m = mom_merge(m, mom_load(red[t]));
+            const int64_t j = o * inner + threadIdx.x;
+            if (KS == 1) axis_finish_store(m, WEIGHTED, j, out_mean, out_std, out_err);
+            else mom_store(partial + (static_cast<int64_t>(seg) * n_out + j) * kMomVals, m);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_axis_final(const double* __restrict__ partial, int KS, int64_t n_out, int weighted,
+                                                    double* __restrict__ out_mean, double* __restrict__ out_std, double* __restrict__ out_err) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; j < n_out; j += stride) {
+        Mom m = mom_load(partial + j * kMomVals);
+        for (int s = 1; s < KS; ++s) m = mom_merge(m, mom_load(partial + (static_cast<int64_t>(s) * n_out + j) * kMomVals));
+        axis_finish_store(m, weighted != 0, j, out_mean, out_std, out_err);
+    }
+}
+
+struct AxisPlan { bool row; int KS; };
+static AxisPlan axis_plan(int64_t outer, int64_t A, int64_t inner) {
+    AxisPlan p;
+    p.row = inner < 16 && A > 32;
+    int64_t ks = 1;
+    if (!p.row) {
+        const int64_t blocks = (outer * inner + 255) / 256;
+        if (blocks < 1024) { ks = (1024 + blocks - 1) / blocks; const int64_t cap = A / 16 > 1 ? A / 16 : 1; if (ks > cap) ks = cap; }
+        if (ks > 256) ks = 256;
+    } else {
+        const int64_t tm = (256 / inner) * inner;
+        if (outer < 1024) { ks = (1024 + outer - 1) / outer; const int64_t cap = (A * inner) / (tm * 8) > 1 ? (A * inner) / (tm * 8) : 1; if (ks > cap) ks = cap; }
+        if (ks > 1024) ks = 1024;
+    }
+    p.KS = static_cast<int>(ks);
+    return p;
+}
+
+// compute_difference / interpolate on BROADCAST operands (modules/measurand.py:621-681 apply NumPy broadcasting to x and y): element
+// strides with 0 on broadcast axes, as hm_binary_op; x and its std share strides (one Measurand), y and its std likewise.
+struct Bcast2K { int64_t shape[HM_MAX_DIMS], st1[HM_MAX_DIMS], st2[HM_MAX_DIMS]; int ndim; };
+__device__ __forceinline__ void bcast_offsets(const Bcast2K& b, int64_t e, int64_t& o1, int64_t& o2) {
+    o1 = 0; o2 = 0;
+    int64_t rem = e;
+    for (int d = b.ndim - 1; d >= 0; --d) {
+        const int64_t i = rem % b.shape[d];
+        rem /= b.shape[d];
+        o1 += i * b.st1[d];
+        o2 += i * b.st2[d];
+    }
+}
+__global__ __launch_bounds__(256) void k_difference_bcast(const double* __restrict__ x, const double* __restrict__ sx,
+                                                          const double* __restrict__ y, const double* __restrict__ sy, double mult,
+                                                          double* __restrict__ ad, double* __restrict__ ads,
+                                                          double* __restrict__ rd, double* __restrict__ rds, int64_t n, const Bcast2K b) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        int64_t ox, oy;
+        bcast_offsets(b, e, ox, oy);
+        const double xv = x[ox], yv = y[oy];
+        const double scale = mult * yv;                     // :634
+        const double a = xv - scale;                        // :635
+        ad[e] = a;
+        rd[e] = a / scale;                                  // :636
+        if (ads) {
+            const double xs = sx ? sx[ox] : 0.0, ys = sy ? sy[oy] : 0.0;
+            const double m1 = mult * ys;
+            ads[e] = sqrt(xs * xs + m1 * m1);               // :652
+            const double u1 = xs / (mult * yv);
+            const double u2 = (ys * xv) / (mult * (yv * yv));
+            rds[e] = sqrt(u1 * u1 + u2 * u2);               // :653
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_interpolate_bcast(const double* __restrict__ x0, const double* __restrict__ s0,
+                                                           const double* __restrict__ x1, const double* __restrict__ s1,
+                                                           double y0, double y1, double y, double* __restrict__ out,
+                                                           double* __restrict__ out_std, int64_t n, const Bcast2K b) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const double a = y1 - y, bb = y - y0, d = y1 - y0;
+    const double ca = (a / d) * (a / d), cb = (bb / d) * (bb / d);
+    for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += stride) {
+        int64_t o0, o1;
+        bcast_offsets(b, e, o0, o1);
+        out[e] = (x0[o0] * a + x1[o1] * bb) / d;            // :665
+        if (out_std) out_std[e] = sqrt((s0 ? s0[o0] : 0.0) * ca + (s1 ? s1[o1] : 0.0) * cb);   // :679 as written
+    }
+}
+
+static bool fill_bcast(Bcast2K& b, int ndim, const int64_t* shape, const int64_t* st1, const int64_t* st2, int64_t& n) {
+    if (ndim < 1 || ndim > HM_MAX_DIMS || !shape || !st1 || !st2) return false;
+    n = 1;
+    b.ndim = ndim;
+    for (int d = 0; d < ndim; ++d) {
+        if (shape[d] < 0 || st1[d] < 0 || st2[d] < 0) return false;
+        b.shape[d] = shape[d]; b.st1[d] = st1[d]; b.st2[d] = st2[d];
+        n *= shape[d];
+    }
+    return true;
+}
+
+}  // namespace hm
+
+extern "C" size_t hm_axis_statistics_workspace_bytes(int64_t outer, int64_t axis_len, int64_t inner) {
+    if (outer < 1 || axis_len < 1 || inner < 1) return 0;
+    const hm::AxisPlan p = hm::axis_plan(outer, axis_len, inner);
+    return p.KS > 1 ? static_cast<size_t>(p.KS) * static_cast<size_t>(outer * inner) * hm::kMomVals * sizeof(double) : 0;
+}
+
+extern "C" int hm_axis_statistics(const double* val, const double* std, int64_t outer, int64_t axis_len, int64_t inner,
+                                  double* out_mean, double* out_std, double* out_err, void* workspace, void* stream) {
+    using namespace hm;
+    if (outer < 1 || axis_len < 1 || inner < 1 || !val || !out_mean || !out_std) return HM_EINVAL;
+    if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
+    const AxisPlan p = axis_plan(outer, axis_len, inner);
+    if (p.KS > 1 && !workspace) return HM_EINVAL;
+    double* partial = static_cast<double*>(workspace);
+    hipStream_t st = as_stream(stream);
+    const int64_t n_out = outer * inner;
+    if (!p.row) {
+        int64_t gx = (n_out + 255) / 256;
+        if (gx > (int64_t{1} << 20)) gx = int64_t{1} << 20;
+        const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(p.KS));
+        if (std) hipLaunchKernelGGL(k_axis_thread<true>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
+        else hipLaunchKernelGGL(k_axis_thread<false>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
+    } else {
+        const dim3 grid(static_cast<unsigned>(p.KS), static_cast<unsigned>(outer < 65535 ? outer : 65535));
+        if (std) hipLaunchKernelGGL(k_axis_row<true>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
+        else hipLaunchKernelGGL(k_axis_row<false>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
+    }
+    if (p.KS > 1)
+        hipLaunchKernelGGL(k_axis_final, dim3(stream_grid(n_out, 256, 8)), dim3(256), 0, st, partial, p.KS, n_out, std ? 1 : 0, out_mean, out_std, out_err);
+    return launch_status();
+}
+
+extern "C" int hm_compute_difference_bcast(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
+                                           double* out_abs, double* out_abs_std, double* out_rel, double* out_rel_std,
+                                           int ndim, const int64_t* shape, const int64_t* strides_x, const int64_t* strides_y, void* stream) {
+    hm::Bcast2K b;
+    int64_t n = 0;
+    if (!hm::fill_bcast(b, ndim, shape, strides_x, strides_y, n)) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!x || !y || !out_abs || !out_rel) return HM_EINVAL;
+    const bool with_std = sx || sy;
+    if (with_std != (out_abs_std != nullptr) || with_std != (out_rel_std != nullptr)) return HM_EINVAL;
+    hipLaunchKernelGGL(hm::k_difference_bcast, dim3(hm::stream_grid(n, 256, 8)), dim3(256), 0, hm::as_stream(stream),
+                       x, sx, y, sy, multiplier, out_abs, out_abs_std, out_rel, out_rel_std, n, b);
+    return hm::launch_status();
+}
+
+extern "C" int hm_interpolate_bcast(const double* x0, const double* s0, const double* x1, const double* s1, double y0, double y1, double y,
+                                    double* out, double* out_std, int ndim, const int64_t* shape, const int64_t* strides0,
+                                    const int64_t* strides1, void* stream) {
+    hm::Bcast2K b;
+    int64_t n = 0;
+    if (!hm::fill_bcast(b, ndim, shape, strides0, strides1, n)) return HM_EINVAL;
+    if (n == 0) return HM_OK;
+    if (!x0 || !x1 || !out || ((s0 || s1) != (out_std != nullptr))) return HM_EINVAL;
+    hipLaunchKernelGGL(hm::k_interpolate_bcast, dim3(hm::stream_grid(n, 256, 8)), dim3(256), 0, hm::as_stream(stream),
+                       x0, s0, x1, s1, y0, y1, y, out, out_std, n, b);
+    return hm::launch_status();
+}

@@ -420,6 +420,13 @@ def plan_merge(frames: Sequence[torch.Tensor], exposures: Sequence[float], icrf,
     if want_sum_w:
         outputs["sum_w"] = torch.empty(out_shape, dtype=_F64, device=dev)
         a.out_sum_w = outputs["sum_w"].data_ptr()
+    # more than HM_MAX_FRAMES frames (or a forced chunking, variant <= -2): hm_merge runs HM_MAX_FRAMES frames per launch and keeps the
+    # running sum of weights in out_sum_w, or in this workspace when the call has none
+    fw = int(nat.lib.hm_merge_frames_workspace_bytes(n if variant > -2 else nat.HM_MAX_FRAMES + 1, rows * W * Cc, int(want_sum_w)))
+    if fw:
+        ws = torch.empty(fw, dtype=_U8, device=dev)
+        a.frames_workspace, a.frames_workspace_bytes = ws.data_ptr(), fw
+        keep.append(ws)
     return MergePlan(a, keep, dev, outputs)
 
 
@@ -570,11 +577,41 @@ def apply_thresholds_(val: torch.Tensor, std: Optional[torch.Tensor], lower: Seq
                   "hm_apply_thresholds")
 
 
+def _bcast_setup(a, sa, b, sb):
+    """Operands of compute_difference / interpolate that do not have one shape: the broadcast result shape and the element strides
+    (0 on broadcast axes) of the two contiguous operands; an operand's std must have the operand's shape (one Measurand)."""
+    try:
+        shape = tuple(torch.broadcast_shapes(a.shape, b.shape))
+    except RuntimeError:
+        raise ValueError("Measurands are not broadcastable.")
+    if len(shape) > nat.HM_MAX_DIMS:
+        raise NotImplementedError(f"more than {nat.HM_MAX_DIMS} dimensions")
+    if len(shape) == 0:
+        shape = (1,)
+    for v, s_ in ((a, sa), (b, sb)):
+        if s_ is not None and s_.shape != v.shape:
+            raise ValueError("Value and std shapes must match.")
+    nd = len(shape)
+    return shape, (C.c_int64 * nd)(*shape), (C.c_int64 * nd)(*_bcast_strides(a, shape)), (C.c_int64 * nd)(*_bcast_strides(b, shape))
+
+
 def compute_difference(x, sx, y, sy, multiplier: float):
-    """modules/measurand.py:620-655 -> (abs, abs_std, rel, rel_std)."""
+    """modules/measurand.py:620-655 -> (abs, abs_std, rel, rel_std). Operands of different shapes broadcast (hm_compute_difference_bcast)."""
     _require_cuda(x, "x")
     _require_cuda(y, "y")
     x, y = x.contiguous(), y.contiguous()
+    if x.shape != y.shape:
+        sx = None if sx is None else sx.contiguous()
+        sy = None if sy is None else sy.contiguous()
+        shape, sh, st1, st2 = _bcast_setup(x, sx, y, sy)
+        with_std = sx is not None or sy is not None
+        mk = lambda on: torch.empty(shape, dtype=_F64, device=x.device) if on else None      # noqa: E731
+        ad, rd, ads, rds = mk(True), mk(True), mk(with_std), mk(with_std)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib.hm_compute_difference_bcast(x.data_ptr(), nat.ptr(sx), y.data_ptr(), nat.ptr(sy), float(multiplier), ad.data_ptr(),
+                                                          nat.ptr(ads), rd.data_ptr(), nat.ptr(rds), len(shape), sh, st1, st2, _stream(x.device)),
+                      "hm_compute_difference_bcast")
+        return ad, ads, rd, rds
     sx = None if sx is None else sx.contiguous()
     sy = None if sy is None else sy.contiguous()
     with_std = sx is not None or sy is not None
@@ -589,11 +626,21 @@ def compute_difference(x, sx, y, sy, multiplier: float):
 
 
 def interpolate(x0, s0, x1, s1, y0: float, y1: float, y: float):
-    """modules/measurand.py:657-681."""
+    """modules/measurand.py:657-681. Operands of different shapes broadcast (hm_interpolate_bcast)."""
     _require_cuda(x0, "x0")
+    _require_cuda(x1, "x1")
     x0, x1 = x0.contiguous(), x1.contiguous()
     s0 = None if s0 is None else s0.contiguous()
     s1 = None if s1 is None else s1.contiguous()
+    if x0.shape != x1.shape:
+        shape, sh, st0, st1 = _bcast_setup(x0, s0, x1, s1)
+        out = torch.empty(shape, dtype=_F64, device=x0.device)
+        out_std = torch.empty(shape, dtype=_F64, device=x0.device) if (s0 is not None or s1 is not None) else None
+        with torch.cuda.device(x0.device):
+            nat.check(nat.lib.hm_interpolate_bcast(x0.data_ptr(), nat.ptr(s0), x1.data_ptr(), nat.ptr(s1), float(y0), float(y1), float(y),
+                                                   out.data_ptr(), nat.ptr(out_std), len(shape), sh, st0, st1, _stream(x0.device)),
+                      "hm_interpolate_bcast")
+        return out, out_std
     out = torch.empty_like(x0)
     out_std = torch.empty_like(x0) if (s0 is not None or s1 is not None) else None
     with torch.cuda.device(x0.device):
@@ -614,6 +661,49 @@ def channel_statistics(val: torch.Tensor, std: Optional[torch.Tensor]):
         nat.check(nat.lib.hm_channel_statistics(val.data_ptr(), nat.ptr(std), val.numel(), Cc, out.data_ptr(), ws.data_ptr(),
                                                 _stream(val.device)), "hm_channel_statistics")
     return {"mean": out[:Cc], "std": out[Cc:2 * Cc], "error": out[2 * Cc:] if std is not None else None}
+
+
+def axis_statistics(val: torch.Tensor, std: Optional[torch.Tensor], axis):
+    """modules/measurand.py:318-350 for any `axis` (int or tuple, NumPy conventions) -> dict(mean, std, error) shaped like NumPy's
+    result (the reduced axes removed). Adjacent reduced axes are reduced in place on the dense (outer, A, inner) view
+    (hm_axis_statistics); axes that are not adjacent are first brought together (the kept axes in order, then the reduced ones:
+    a layout copy)."""
+    _require_cuda(val, "val")
+    nd = val.dim()
+    axes = sorted({a % nd for a in ((axis,) if isinstance(axis, int) else tuple(axis))})
+    if not axes or any(not -nd <= a < nd for a in ((axis,) if isinstance(axis, int) else tuple(axis))):
+        raise ValueError(f"axis {axis} is out of bounds for an array of dimension {nd}")
+    if std is not None:
+        _require_cuda(std, "std")
+        if std.shape != val.shape:
+            raise ValueError("Value and std shapes must match.")
+        std = std.to(_F64)
+    kept = [d for d in range(nd) if d not in axes]
+    out_shape = tuple(val.shape[d] for d in kept)
+    if axes != list(range(axes[0], axes[-1] + 1)):
+        perm = kept + axes
+        val = val.permute(perm)
+        std = None if std is None else std.permute(perm)
+        lead = len(kept)
+        axes = list(range(lead, nd))
+    val = val.contiguous()
+    std = None if std is None else std.contiguous()
+    sh = list(val.shape)
+    outer = int(np.prod(sh[:axes[0]], dtype=np.int64))
+    A = int(np.prod(sh[axes[0]:axes[-1] + 1], dtype=np.int64))
+    inner = int(np.prod(sh[axes[-1] + 1:], dtype=np.int64))
+    if outer * A * inner == 0:
+        raise ValueError("statistics of an empty array")
+    dev = val.device
+    mean = torch.empty(out_shape, dtype=_F64, device=dev)
+    sd = torch.empty(out_shape, dtype=_F64, device=dev)
+    err = torch.empty(out_shape, dtype=_F64, device=dev) if std is not None else None
+    ws_b = int(nat.lib.hm_axis_statistics_workspace_bytes(outer, A, inner))
+    ws = torch.empty(max(1, ws_b // 8), dtype=_F64, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib.hm_axis_statistics(val.data_ptr(), nat.ptr(std), outer, A, inner, mean.data_ptr(), sd.data_ptr(), nat.ptr(err),
+                                             ws.data_ptr(), _stream(dev)), "hm_axis_statistics")
+    return {"mean": mean, "std": sd, "error": err}
 
 
 def pair_statistics(x, sx, y, sy, multiplier: float):

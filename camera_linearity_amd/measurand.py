@@ -16,10 +16,10 @@ Extra: `val` may be a uint8 DN tensor (the reference accepts integer arrays in l
 measurand.py:505); `HipMeasurand.from_dn()` keeps an 8-bit frame as DNs in HBM (1 byte/element
 instead of 8) and materialises DN/255 (modules/image_set.py:223) only when `.val` is read.
 
-Rows "next" of SURVEY.md 8f-1: apply_thresholds, compute_difference, interpolate and
-compute_dimension_statistics over the image axes run as HIP kernels (csrc/hm_stats.hip); exotic shapes
-(more than 4 channels, other reduction axes, broadcasting operands), extract and the host-side histogram
-use torch / NumPy on the same tensors so that the class surface is complete.
+Rows "next" of SURVEY.md 8f-1: apply_thresholds, compute_difference, interpolate (equal shapes or broadcasting operands),
+compute_dimension_statistics (any axis or axis tuple), extract and compute_channel_histogram run as HIP kernels
+(csrc/hm_stats.hip, hm_ops.hip); what a kernel does not cover raises (more than 32 channels in apply_thresholds, more
+than 4 channels in the histogram, kernel density estimates) - nothing is computed with torch or NumPy arithmetic.
 """
 from __future__ import annotations
 
@@ -363,8 +363,7 @@ class HipMeasurand(AbstractMeasurand):
             sorted(a % values.dim() for a in ((axis,) if isinstance(axis, int) else tuple(axis))) == list(range(values.dim() - 1))
         if all_but_last and values.shape[-1] <= 4:
             return _engine().channel_statistics(values, self.std)                # hm_channel_statistics
-        raise NotImplementedError("hm_channel_statistics reduces over all axes (axis=None) or over all but the last axis of an "
-                                  "array with at most 4 channels (axis=(0, 1) of an image) - the two cases the reference uses")
+        return _engine().axis_statistics(values, self.std, axis)                 # hm_axis_statistics: any other axis / axis tuple
 
     def compute_kernel_density_estimate(self, data_points: int, included_range=None, channels=None, use_std: bool = False):
         """modules/measurand.py:716-761 is a NumPy-only plotting helper of the reference (scipy.stats.gaussian_kde on host arrays)
@@ -391,10 +390,9 @@ class HipMeasurand(AbstractMeasurand):
         xv, yv = x._f64(), y._f64()
         if not xv.is_cuda:
             raise RuntimeError("compute_difference needs the images on the device (there is no CPU fallback)")
-        if xv.shape != yv.shape:
-            raise NotImplementedError("hm_compute_difference takes two images of the same shape (the reference's only use, "
-                                      "ImageSet.compute_difference of two frames of one series)")
-        ad, ads, rd, rds = _engine().compute_difference(xv, x.std, yv, y.std, multiplier)   # hm_compute_difference
+        if not is_broadcastable(xv.shape, yv.shape):
+            raise ValueError("Measurands are not broadcastable.")
+        ad, ads, rd, rds = _engine().compute_difference(xv, x.std, yv, y.std, multiplier)   # hm_compute_difference(_bcast)
         return cls(ad, ads), cls(rd, rds)
 
     @staticmethod
@@ -403,9 +401,9 @@ class HipMeasurand(AbstractMeasurand):
         cls = x0.__class__
         if not x0._f64().is_cuda:
             raise RuntimeError("interpolate needs the images on the device (there is no CPU fallback)")
-        if x0.shape != x1.shape:
-            raise NotImplementedError("hm_interpolate takes two images of the same shape")
-        res, res_std = _engine().interpolate(x0._f64(), x0.std, x1._f64(), x1.std, y0, y1, y)   # hm_interpolate
+        if not is_broadcastable(x0.shape, x1.shape):
+            raise ValueError("Measurands are not broadcastable.")
+        res, res_std = _engine().interpolate(x0._f64(), x0.std, x1._f64(), x1.std, y0, y1, y)   # hm_interpolate(_bcast)
         return cls(res, res_std)
 
 

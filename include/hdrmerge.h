@@ -32,15 +32,18 @@
 extern "C" {
 #endif
 
-#define HM_ABI_VERSION 1
+/* ABI history. 1: first release (hm_merge_args 264 bytes), later grown by hot_workspace / hot_workspace_bytes (280 bytes) without a bump.
+ * 2: frames_workspace / frames_workspace_bytes (296 bytes), hm_merge_frames_workspace_bytes(), stacks of more than HM_MAX_FRAMES
+ *    frames; hm_merge still accepts the 264- and 280-byte layouts (the missing tail reads as "no workspace").            */
+#define HM_ABI_VERSION 2
 #define HM_BITS 256
-#define HM_MAX_FRAMES 32     /* frames per fused merge launch */
+#define HM_MAX_FRAMES 32     /* frames per merge LAUNCH; hm_merge takes any number of frames (32 per launch, see frames_workspace) */
 #define HM_MAX_CHANNELS 4
 
 enum {
     HM_OK = 0,
     HM_EINVAL = -1,        /* bad argument (null pointer, non-positive size, bad enum)        */
-    HM_EUNSUPPORTED = -2,  /* valid request this build cannot serve (N > HM_MAX_FRAMES, C > 4) */
+    HM_EUNSUPPORTED = -2,  /* valid request this build cannot serve (C > 4; N > HM_MAX_FRAMES without frames_workspace / out_sum_w) */
     HM_EALIGN = -3,        /* a float64 buffer is not 8-byte aligned                           */
     HM_ELAUNCH = -4,       /* the HIP runtime rejected the launch (hipGetLastError != success) */
     HM_ENODEVICE = -5,     /* no usable gfx950 device                                          */
@@ -110,9 +113,10 @@ int hm_linearize_f64(const double* v, const double* std, const double* icrf, con
  * ------------------------------------------------------------------------------------------ */
 typedef struct hm_merge_args {
     uint32_t struct_size;         /* sizeof(hm_merge_args), for ABI evolution                       */
-    int32_t  n_frames;            /* N, 1..HM_MAX_FRAMES, ascending exposure                        */
+    int32_t  n_frames;            /* N >= 1, ascending exposure (N > HM_MAX_FRAMES: see frames_workspace) */
     int32_t  channels;            /* C, 1..HM_MAX_CHANNELS                                          */
-    int32_t  variant;             /* 0 = library default; >0 selects a tuning variant (tools/tune_merge.py), <0 forces the generic kernel */
+    int32_t  variant;             /* 0 = library default; >0 selects a tuning variant (tools/tune_merge.py), -1 forces the generic kernel,
+                                     <= -2 forces the chunked path with -variant frames per launch (tests) */
     int64_t  height;              /* H of the full image                                            */
     int64_t  width;               /* W                                                              */
     int64_t  row0, rows;          /* output rows of this call                                       */
@@ -153,6 +157,14 @@ typedef struct hm_merge_args {
      * anything smaller selects the NULL path); owned by this call until it has completed on `stream`.                      */
     void*    hot_workspace;
     size_t   hot_workspace_bytes;
+
+    /* Stacks of more than HM_MAX_FRAMES frames (the reference's loop has no limit, modules/exposure_series.py:334,372) are merged
+     * HM_MAX_FRAMES frames per launch with the running sums in memory: the numerator in out_val, the variance in out_std, and the sum
+     * of weights in out_sum_w when the call has one, else HERE: device memory, 16-byte aligned, hm_merge_frames_workspace_bytes()
+     * bytes (one float64 per output element), owned by the call until it has completed on `stream`. NULL with N > HM_MAX_FRAMES and
+     * no out_sum_w: HM_EUNSUPPORTED. Same operation sequence per element as the one-launch kernels (bit-identical for any chunking).  */
+    void*    frames_workspace;
+    size_t   frames_workspace_bytes;
 } hm_merge_args;
 
 int hm_merge(const hm_merge_args* args /*[host]*/, void* stream);
@@ -160,6 +172,9 @@ int hm_merge(const hm_merge_args* args /*[host]*/, void* stream);
  * (counters + a table of 8 bytes per 65 536 elements + the queue: a quarter of the elements / one entry). */
 size_t hm_merge_hot_workspace_bytes(int64_t n_elems);
 size_t hm_merge_hot_workspace_min_bytes(int64_t n_elems);
+/* Bytes of hm_merge_args.frames_workspace for a call with n_frames frames and n_elems = rows * W * C output elements: 0 up to
+ * HM_MAX_FRAMES frames or when the call has an out_sum_w, else 8 * n_elems. */
+size_t hm_merge_frames_workspace_bytes(int n_frames, int64_t n_elems, int has_out_sum_w);
 
 /* Algorithmic HBM bytes one hm_merge call moves: every input byte once, every output
  * byte once, LUTs excluded. Used by bench.py for roofline.achieved. */
@@ -284,6 +299,23 @@ int hm_channel_histogram(const double* val, const double* std /*nullable*/, int6
 size_t hm_channel_statistics_workspace_bytes(void);
 int hm_channel_statistics(const double* val, const double* std /*nullable*/, int64_t n, int C,
                           double* out, void* workspace, void* stream);
+/* compute_dimension_statistics over ANY axis (modules/measurand.py:318-350 pass `axis` to NumPy's nan-reductions): the array is the
+ * dense (outer, axis_len, inner) block and is reduced over its middle dimension; out_mean / out_std / out_err are outer * inner
+ * float64 each (out_err nullable; NaN without std). Several reduced axes = their product when adjacent (the caller brings axes that
+ * are not adjacent together with a layout copy). workspace: hm_axis_statistics_workspace_bytes() bytes (0 = none needed). */
+size_t hm_axis_statistics_workspace_bytes(int64_t outer, int64_t axis_len, int64_t inner);
+int hm_axis_statistics(const double* val, const double* std /*nullable*/, int64_t outer, int64_t axis_len, int64_t inner,
+                       double* out_mean, double* out_std, double* out_err /*nullable*/, void* workspace, void* stream);
+/* compute_difference / interpolate on operands that BROADCAST against each other (the reference applies NumPy broadcasting,
+ * modules/measurand.py:621-681): `shape` is the broadcast result shape (ndim <= HM_MAX_DIMS), strides are in ELEMENTS with 0 on
+ * broadcast axes (as hm_binary_op); an operand and its std share strides. Outputs are dense arrays of that shape. */
+int hm_compute_difference_bcast(const double* x, const double* sx, const double* y, const double* sy, double multiplier,
+                                double* out_abs, double* out_abs_std, double* out_rel, double* out_rel_std,
+                                int ndim, const int64_t* shape /*[host]*/, const int64_t* strides_x /*[host]*/,
+                                const int64_t* strides_y /*[host]*/, void* stream);
+int hm_interpolate_bcast(const double* x0, const double* s0, const double* x1, const double* s1, double y0, double y1, double y,
+                         double* out, double* out_std, int ndim, const int64_t* shape /*[host]*/, const int64_t* strides0 /*[host]*/,
+                         const int64_t* strides1 /*[host]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Upstream producer: welford_algorithm, modules/video_processing.py:161-219.

@@ -357,14 +357,22 @@ def test_measurand_methods_run_their_hip_kernels(M):
     ref_all = orc.dimension_statistics(a, 0.1 * a, None)
     for key in ("mean", "std", "error"):
         np.testing.assert_allclose(float(st_all[key]), float(ref_all[key]), rtol=1e-12)
-    with pytest.raises(NotImplementedError):
-        A.compute_dimension_statistics(axis=1)
+    st1 = ran("hm_axis_statistics", lambda: A.compute_dimension_statistics(axis=1))   # any other axis: hm_axis_statistics
+    ref1 = orc.dimension_statistics(a, 0.1 * a, 1)
+    for key in ("mean", "std", "error"):
+        np.testing.assert_allclose(st1[key].cpu().numpy(), ref1[key], rtol=1e-11)
     ran("hm_compute_difference", lambda: A.compute_difference(A, B, 0.5))
     ran("hm_interpolate", lambda: A.interpolate(A, B, 1.0, 3.0, 1.5))
-    with pytest.raises(NotImplementedError):
-        A.compute_difference(A, M(b[:, :, :1]), 0.5)
-    with pytest.raises(NotImplementedError):
-        A.interpolate(A, M(b[:1]), 1.0, 3.0, 1.5)
+    d_abs, d_rel = ran("hm_compute_difference_bcast", lambda: A.compute_difference(A, M(b[:, :, :1].copy()), 0.5))   # broadcasting operands
+    want = orc.compute_difference(a, 0.1 * a, b[:, :, :1], None, 0.5)
+    np.testing.assert_allclose(d_abs.val.cpu().numpy(), want[0], rtol=1e-15)
+    np.testing.assert_allclose(d_rel.std.cpu().numpy(), want[3], rtol=1e-14)
+    ip = ran("hm_interpolate_bcast", lambda: A.interpolate(A, M(b[:1].copy(), 0.2 * b[:1]), 1.0, 3.0, 1.5))
+    want = orc.interpolate(a, 0.1 * a, b[:1], 0.2 * b[:1], 1.0, 3.0, 1.5)
+    np.testing.assert_allclose(ip.val.cpu().numpy(), want[0], rtol=1e-15)
+    np.testing.assert_allclose(ip.std.cpu().numpy(), want[1], rtol=1e-14)
+    with pytest.raises(ValueError):
+        A.compute_difference(A, M(b[:, :5]), 0.5)                                     # not broadcastable (modules/measurand.py:112)
     ran("hm_binary_op", lambda: A ** B)
     ran("hm_pow_scalar", lambda: A ** 2)
     from camera_linearity_amd import engine
@@ -765,3 +773,52 @@ def test_process_linearity_thresholds_in_place(use_std, h, w, n):
     for p, (m_, s__) in zip(series.exposure_pairs, first):
         assert np.array_equal(p.absolute_stats["mean"].cpu().numpy(), m_.cpu().numpy(), equal_nan=True)
         assert np.array_equal(p.relative_stats["std"].cpu().numpy(), s__.cpu().numpy(), equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------ statistics over any axis
+@pytest.mark.parametrize("shape,axis", [((40, 50, 3), 0), ((40, 50, 3), 1), ((40, 50, 3), 2), ((40, 50, 3), -1), ((40, 50, 3), (0, 2)),
+                                        ((40, 50, 3), (1, 2)), ((40, 50, 3), (0, 1, 2)), ((5, 2000, 3), 1), ((3000, 7), 0), ((3000, 7), 1),
+                                        ((2, 3, 4, 5, 6), (1, 3)), ((70000,), 0), ((1, 100000, 2), 1), ((300, 40), 0), ((9, 6), (0,)),
+                                        ((64, 64, 8), (0, 1)), ((33, 17, 20), 1)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dimension_statistics_any_axis(M, shape, axis, weighted):
+    """compute_dimension_statistics(axis) for single axes, adjacent and non-adjacent axis tuples, long and short axes, few and many
+    outputs (both kernels of hm_axis_statistics, with and without the segment split) against the oracle's NumPy nan-reductions
+    (modules/measurand.py:318-350), NaNs in the values and in the stds. rtol 1e-11 (one-pass moments against two NumPy passes)."""
+    rng = np.random.default_rng(hash((shape, str(axis), weighted)) % (2 ** 32))
+    a = rng.random(shape) + 0.25
+    s_ = 0.05 + 0.1 * rng.random(shape) if weighted else None
+    a[rng.random(shape) < 0.05] = np.nan
+    if weighted:
+        s_[rng.random(shape) < 0.03] = np.nan
+    ax = (axis,) if isinstance(axis, int) else tuple(axis)
+    leading = sorted(x % a.ndim for x in ax) == list(range(len(ax)))
+    with np.errstate(all="ignore"):
+        if not weighted or leading:
+            ref = orc.dimension_statistics(a, s_, axis)
+        else:
+            # the reference's weighted branch subtracts the REDUCED mean from the values (modules/measurand.py:344): that only broadcasts
+            # when the reduced axes lead; for the other axes it raises (or, on coinciding sizes, mis-broadcasts). The kernel computes what
+            # the formula means - the mean kept along the reduced axes - which is the same expression with keepdims:
+            w = 1 / s_
+            sw = np.nansum(w, axis=ax, keepdims=True)
+            mean = np.nansum(a * w, axis=ax, keepdims=True) / sw
+            sd = np.sqrt(np.nansum(w * (a - mean) ** 2, axis=ax, keepdims=True) / sw)
+            ref = dict(mean=np.squeeze(mean, axis=ax), std=np.squeeze(sd, axis=ax), error=np.nanmean(s_, axis=ax))
+    got = M(a.copy(), None if s_ is None else s_.copy()).compute_dimension_statistics(axis=axis)
+    for key in ("mean", "std") + (("error",) if weighted else ()):
+        g_ = got[key].cpu().numpy()
+        assert g_.shape == np.asarray(ref[key]).shape, (key, g_.shape, np.asarray(ref[key]).shape)
+        np.testing.assert_allclose(g_, ref[key], rtol=1e-11, atol=1e-300, equal_nan=True)
+    if not weighted:
+        assert got["error"] is None
+
+
+def test_dimension_statistics_all_nan_column_and_errors(M):
+    a = np.ones((6, 5, 3))
+    a[:, 2, 1] = np.nan                                              # a whole reduction line of NaNs: NumPy gives NaN (with a warning)
+    got = M(a).compute_dimension_statistics(axis=0)
+    m = got["mean"].cpu().numpy()
+    assert np.isnan(m[2, 1]) and np.all(m[np.isfinite(m)] == 1.0) and np.isnan(got["std"].cpu().numpy()[2, 1])
+    with pytest.raises(ValueError):
+        M(a).compute_dimension_statistics(axis=3)

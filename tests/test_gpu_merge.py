@@ -523,8 +523,7 @@ def test_merge_argument_errors(eng):
         eng.merge([f], [1.0], icrf[:, :2])                        # ICRF shape
     with pytest.raises(ValueError):
         eng.merge([f], [1.0], icrf, None, [dev(np.zeros((4, 4, 3)))])   # std without ICRF_diff
-    with pytest.raises(NotImplementedError):
-        eng.merge([f] * 33, [1.0] * 33, icrf)                     # > HM_MAX_FRAMES
+    assert eng.merge([f] * 33, [1.0] * 33, icrf)["val"].shape == (4, 4, 3)   # > HM_MAX_FRAMES: chunked, no longer an error
     with pytest.raises(RuntimeError):
         eng.merge([torch.zeros((4, 4, 3), dtype=torch.uint8)], [1.0], icrf)   # host tensor: no CPU fallback
     d = dev(np.zeros((4, 4, 3), np.uint8))
@@ -1242,3 +1241,69 @@ def test_monochrome_val_only_kernel(eng, n):
         plan.launch()
         gen = eng.merge(frames, t, icrf, diff, stds, flat=fl, flat_std=fstd, ff_mean=[0.79], ff_std_mean=[0.002], variant=-1)
         assert torch.equal(plan.outputs["val"], gen["val"]) and torch.equal(plan.outputs["std"], gen["std"])
+
+
+# ------------------------------------------------------------------ stacks of more than HM_MAX_FRAMES frames (chunked path)
+@pytest.mark.parametrize("chunk", [2, 3, 5])
+@pytest.mark.parametrize("mode", ["val", "std", "full", "f64", "f64std", "sumw_only"])
+def test_chunked_merge_bit_identical_to_one_launch(eng, chunk, mode):
+    """variant = -chunk forces hm_merge_chunk.hip's path (running sums in memory between launches of `chunk` frames) on a 7-frame
+    stack: every mode gives the bits of merge_generic (variant -1) - the chunking does not show in the result. Odd element count
+    (two-elements-per-thread body + a one-element tail)."""
+    n, h, w = 7, 37, 21
+    frames, stds, t = orc.synthetic_stack(90 + chunk, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    rng = np.random.default_rng(chunk)
+    f64 = mode.startswith("f64")
+    fr = [dev(orc.unit_from_u8(f) + (rng.random(f.shape) - 0.5) * 1e-3) if f64 else dev(f) for f in frames]
+    sd = [dev(s_) for s_ in stds] if mode in ("std", "full", "f64std") else None
+    kw = {}
+    if mode == "full":
+        dark = (rng.random((h, w, 3)) < 0.03).astype(np.uint8) * 200
+        dark2 = (rng.random((h, w, 3)) < 0.03).astype(np.uint8) * 220
+        kw.update(darks=[None, dev(dark), dev(dark2), dev(dark), None, dev(dark2), dev(dark)], dark_min=[256, 100, 100, 100, 256, 100, 100], median_k=3,
+                  flat=dev(rng.integers(180, 230, size=(h, w, 3)).astype(np.uint8)), flat_std=dev(np.full((h, w, 3), 0.002)),
+                  ff_mean=[0.8, 0.81, 0.79], ff_std_mean=[0.002] * 3, want_sum_w=True)
+    if mode == "sumw_only":
+        kw.update(want_sum_w=True, want_val=False)
+    a = eng.merge(fr, t, icrf, diff if sd else None, sd, variant=-chunk, **kw)
+    b = eng.merge(fr, t, icrf, diff if sd else None, sd, variant=-1, **kw)
+    assert set(a) == set(b) and len(a) >= 1
+    for key in a:
+        assert torch.equal(a[key], b[key]), (key, mode, chunk)
+    # a view that starts at an odd byte / 8-byte-only aligned float64: the one-element-per-thread kernels
+    if mode in ("val", "f64"):
+        big = [torch.empty(h * w * 3 + 1, dtype=f_.dtype, device="cuda") for f_ in fr]
+        fo = []
+        for bt, f_ in zip(big, fr):
+            bt[1:] = f_.reshape(-1)
+            fo.append(bt[1:].view(h, w, 3))
+        c = eng.merge(fo, t, icrf, variant=-chunk)
+        assert torch.equal(c["val"], b["val"])
+
+
+@pytest.mark.parametrize("n,with_std,f64", [(33, False, False), (40, True, False), (70, True, False), (45, False, True), (36, True, True)])
+def test_merge_more_than_32_frames(eng, n, with_std, f64):
+    """The reference's merge loop has no frame limit (modules/exposure_series.py:334,372): stacks of 33-70 frames against the oracle,
+    with a dark map on some frames and a flat field. val rtol 1e-12 (uint8) / 1e-11 (float64 frames), std 1e-9."""
+    h, w = 24, 40
+    frames, stds, t = orc.synthetic_stack(200 + n, n, h, w, with_std=with_std)
+    t = np.asarray(t) * 2.0 ** (-(n // 2))                      # keep the long exposures finite and the ratios of the recipe
+    icrf, diff = orc.synthetic_icrf()
+    rng = np.random.default_rng(n)
+    dark = (rng.random((h, w, 3)) < 0.02).astype(np.uint8) * 210
+    darks_h = [orc.unit_from_u8(dark) if i % 3 == 1 else None for i in range(n)]
+    flat = rng.integers(180, 230, size=(h, w, 3)).astype(np.uint8)
+    flat_std = np.full((h, w, 3), 0.002)
+    m = orc.flat_roi_mean(orc.unit_from_u8(flat), h, w, 0.2)
+    s_ = orc.flat_roi_mean(flat_std, h, w, 0.2)
+    fh = [orc.unit_from_u8(f) for f in frames] if f64 else frames
+    ref = orc.merge(fh, t, icrf, diff if with_std else None, stds=stds if with_std else None, darks=darks_h, dark_threshold=0.5, median_k=3,
+                    flat=orc.unit_from_u8(flat), flat_std=flat_std, ff_mean=m, ff_std_mean=s_)
+    dmin = eng.dark_min_dn(1.0, 0.5)
+    out = eng.merge([dev(f) for f in fh], t, icrf, diff if with_std else None, [dev(x) for x in stds] if with_std else None,
+                    darks=[dev(dark) if i % 3 == 1 else None for i in range(n)], dark_min=[dmin if i % 3 == 1 else 256 for i in range(n)], median_k=3,
+                    flat=dev(flat), flat_std=dev(flat_std) if with_std else None, ff_mean=m, ff_std_mean=s_ if with_std else None)
+    close(host(out["val"]), ref["val_ff"], F64_RTOL if f64 else VAL_RTOL)
+    if with_std:
+        close(host(out["std"]), ref["std_ff"], STD_RTOL)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(nat.EXPORTED_SYMBOLS), declared ^ set(nat.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(nat.lib, name)
-    assert nat.lib.hm_version() == 1
+    assert nat.lib.hm_version() == nat.HM_ABI_VERSION == 2
     assert nat.strerror(0) == "ok" and "geometry" in nat.strerror(nat.HM_ESHAPE)
     assert "unknown" in nat.strerror(-99)
 
@@ -33,9 +33,10 @@ def test_library_exports_every_declared_symbol():
 def test_merge_args_layout_matches_header():
     from camera_linearity_amd import _native as nat
     # offsets of include/hdrmerge.h's struct on LP64 (checked against a C compile in the build container)
-    assert C.sizeof(nat.MergeArgs) == 280
+    assert C.sizeof(nat.MergeArgs) == 296
     assert nat.MergeArgs.frames_u8.offset == 64 and nat.MergeArgs.ff_mean.offset == 176
     assert nat.MergeArgs.out_sum_w.offset == 256 and nat.MergeArgs.hot_workspace.offset == 264
+    assert nat.MergeArgs.frames_workspace.offset == 280
 
 
 def test_argument_validation_without_device():
@@ -46,9 +47,9 @@ def test_argument_validation_without_device():
     a.struct_size = 1
     assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EINVAL            # wrong struct size
     a.struct_size = C.sizeof(nat.MergeArgs)
-    a.n_frames, a.channels, a.height, a.width, a.rows, a.buf_rows = 40, 3, 4, 4, 4, 4
-    assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EUNSUPPORTED      # > HM_MAX_FRAMES
-    a.n_frames = 2
+    a.n_frames, a.channels, a.height, a.width, a.rows, a.buf_rows = 2, 5, 4, 4, 4, 4
+    assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EUNSUPPORTED      # > HM_MAX_CHANNELS
+    a.channels = 3
     assert nat.lib.hm_merge(C.byref(a), None) == nat.HM_EINVAL            # no frames given
     assert nat.lib.hm_merge_algorithmic_bytes(C.byref(a)) == 2 * 48       # 2 uint8 frames, no outputs requested
     assert nat.lib.hm_linearize_u8(None, None, None, None, None, None, 0, 3, 3, None) == nat.HM_EINVAL
@@ -221,12 +222,13 @@ def test_oracle_is_test_infrastructure_only():
 
 
 # ---------------------------------------------------------------------------------------------- dispatch (no GPU needed)
-def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False, variant=0, align=0, darks=False, hot_ws=False):
+def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False, variant=0, align=0, darks=False, hot_ws=False,
+              frames_ws=False, struct_size=None):
     """hm_merge_describe runs hm_merge's own dispatch with launching switched off: pointers only need to look aligned."""
     import ctypes as C_
     from camera_linearity_amd import _native as nat
     a = nat.MergeArgs()
-    a.struct_size = C_.sizeof(nat.MergeArgs)
+    a.struct_size = C_.sizeof(nat.MergeArgs) if struct_size is None else struct_size
     a.n_frames, a.channels, a.variant = n, C, variant
     a.height = a.rows = a.buf_rows = H
     a.width = W
@@ -259,6 +261,8 @@ def _describe(n=7, C=3, H=64, W=64, std=False, flat=False, sumw=False, f64=False
         keep += [dk, dm]
         if hot_ws:
             a.hot_workspace, a.hot_workspace_bytes = base * 91, nat.lib.hm_merge_hot_workspace_bytes(H * W * C)
+    if frames_ws:
+        a.frames_workspace, a.frames_workspace_bytes = base * 92, 8 * H * W * C
     buf = C_.create_string_buffer(512)
     rc = nat.lib.hm_merge_describe(C_.byref(a), buf, 512)
     return rc, buf.value.decode()
@@ -300,7 +304,19 @@ def test_merge_dispatch_table():
     assert _describe(7, align=1)[1] == "merge_generic<f64in=0,std=0>"
     assert _describe(7, variant=-1)[1] == "merge_generic<f64in=0,std=0>"
     assert _describe(7, variant=1120)[1] == "merge_u8_fast<N=7,U=2,flat=0,sum_w=0>"        # round 1's kernel stays reachable for A/B runs
-    assert _describe(33)[0] == nat.HM_EUNSUPPORTED
+    # more than HM_MAX_FRAMES frames: 32 per launch with the running sums in memory - the sum of weights in out_sum_w or the workspace
+    assert _describe(33)[0] == nat.HM_EUNSUPPORTED                                           # neither given
+    assert _describe(33, frames_ws=True) == (0, "merge_chunk<f64in=0,val,hot=0,vec=2>(N=33 in chunks of 32)")
+    assert _describe(70, std=True, sumw=True, darks=True)[1] == "merge_chunk<f64in=0,S + std,hot=1,vec=2>(N=70 in chunks of 32)"
+    assert _describe(40, f64=True, frames_ws=True, align=8)[1] == "merge_chunk<f64in=1,val,hot=0,vec=1>(N=40 in chunks of 32)"
+    assert _describe(7, variant=-3, frames_ws=True)[1] == "merge_chunk<f64in=0,val,hot=0,vec=2>(N=7 in chunks of 3)"
+    assert nat.lib.hm_merge_frames_workspace_bytes(32, 1000, 0) == 0 and nat.lib.hm_merge_frames_workspace_bytes(33, 1000, 0) == 8000
+    assert nat.lib.hm_merge_frames_workspace_bytes(33, 1000, 1) == 0
+    # callers built against the two ABI-1 layouts of hm_merge_args (264 bytes: no hot-pixel workspace; 280: with it) still work
+    assert _describe(7, struct_size=264) == (0, "merge_u8_val3<N=7,U=4,PF=1,MAP=3>")
+    assert _describe(7, std=True, darks=True, hot_ws=True, struct_size=264)[1].endswith("merge_fixup_hot<f64in=0,std=1>")   # the workspace fields are past the old struct's end
+    assert _describe(7, std=True, darks=True, hot_ws=True, struct_size=280)[1].endswith("merge_patch_hot<f64in=0,std=1>")
+    assert _describe(7, struct_size=272)[0] == nat.HM_EINVAL
 
 
 def test_probe_and_tuning_variants_are_rejected_by_the_default_library():
