@@ -357,8 +357,8 @@ def test_measurand_methods_run_their_hip_kernels(M):
     ref_all = orc.dimension_statistics(a, 0.1 * a, None)
     for key in ("mean", "std", "error"):
         np.testing.assert_allclose(float(st_all[key]), float(ref_all[key]), rtol=1e-12)
-    st1 = ran("hm_axis_statistics", lambda: A.compute_dimension_statistics(axis=1))   # any other axis: hm_axis_statistics
-    ref1 = orc.dimension_statistics(a, 0.1 * a, 1)
+    st1 = ran("hm_axis_statistics", lambda: A.compute_dimension_statistics(axis=0))   # any other axis: hm_axis_statistics
+    ref1 = orc.dimension_statistics(a, 0.1 * a, 0)
     for key in ("mean", "std", "error"):
         np.testing.assert_allclose(st1[key].cpu().numpy(), ref1[key], rtol=1e-11)
     ran("hm_compute_difference", lambda: A.compute_difference(A, B, 0.5))

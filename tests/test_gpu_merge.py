@@ -1298,8 +1298,12 @@ def test_merge_more_than_32_frames(eng, n, with_std, f64):
     m = orc.flat_roi_mean(orc.unit_from_u8(flat), h, w, 0.2)
     s_ = orc.flat_roi_mean(flat_std, h, w, 0.2)
     fh = [orc.unit_from_u8(f) for f in frames] if f64 else frames
-    ref = orc.merge(fh, t, icrf, diff if with_std else None, stds=stds if with_std else None, darks=darks_h, dark_threshold=0.5, median_k=3,
-                    flat=orc.unit_from_u8(flat), flat_std=flat_std, ff_mean=m, ff_std_mean=s_)
+    if with_std:
+        ref = orc.merge(fh, t, icrf, diff, stds=stds, darks=darks_h, dark_threshold=0.5, median_k=3,
+                        flat=orc.unit_from_u8(flat), flat_std=flat_std, ff_mean=m, ff_std_mean=s_)
+    else:                                                        # val-only: measurand.py:602 alone
+        ref = orc.merge(fh, t, icrf, None, darks=darks_h, dark_threshold=0.5, median_k=3)
+        ref["val_ff"] = (ref["val"] / orc.unit_from_u8(flat)) * m
     dmin = eng.dark_min_dn(1.0, 0.5)
     out = eng.merge([dev(f) for f in fh], t, icrf, diff if with_std else None, [dev(x) for x in stds] if with_std else None,
                     darks=[dev(dark) if i % 3 == 1 else None for i in range(n)], dark_min=[dmin if i % 3 == 1 else 256 for i in range(n)], median_k=3,
