@@ -115,35 +115,63 @@ def rank_report(dist, a, dev, elapsed, avg_us):
 DARK_THR = 0.05                 # pixel threshold of the dark maps (settings.DARK_THRESHOLD)
 
 
-def _kernel_key(name):
-    """('merge_u8_val3', (7, 4, 1, 0)) from either the demangled symbol rocprof prints or the library's own description."""
-    import re
-    m = re.search(r"(merge_\w+)\s*<([^>]*)>", name or "")
-    if not m:
-        return None
-    nums = tuple(int(x) for x in re.findall(r"-?\d+", m.group(2)))
-    # merge_u8_val3's four parameters are all integers in both spellings; the other kernels' bool parameters print as true / false in
-    # the demangled symbol and as 0 / 1 in the library's description: compare their name and first parameter (N or C)
-    return (m.group(1), nums if m.group(1) == "merge_u8_val3" else nums[:1])
+# ---- counter records (tools/profile.sh -> tools/summarize_profile.py -> profiles/r04_pmc_counters.json) --------------------------------
+# A record holds what the PMC passes measured per launch of a workload's kernel (HBM bytes; VALU wave-instructions for the FP64-bound
+# kernels), the kernel's name, the commit and a HASH OF THE KERNEL'S SOURCE FILES at collection time. bench.py prints a record only while
+# that hash is the hash of the sources the loaded library was built from in this tree: after any edit of the kernel's file the line says
+# `traffic: null, traffic_stale: true` until the profile is re-run (round 3 matched records by kernel name only).
+COUNTER_RECORDS = "profiles/r04_pmc_counters.json"
+_KERNEL_SOURCES = {"merge": ("hm_merge.hip", "hm_common.h"), "linearity": ("hm_stats.hip", "hm_common.h"), "welford": ("hm_welford.hip", "hm_common.h"),
+                   "energy": ("hm_energy.hip", "hm_common.h")}
+
+
+def kernel_source_hash(workload):
+    """sha256 (first 16 hex digits) of the csrc files the workload's dominant kernel is compiled from."""
+    import hashlib
+    fam = "linearity" if workload.startswith("linearity") else workload if workload in ("welford", "energy") else "merge"
+    h = hashlib.sha256()
+    for name in _KERNEL_SOURCES[fam]:
+        h.update((ROOT / "camera_linearity_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def counter_record(workload):
+    """(record | None, stale): the workload's PMC record when it was collected on the current kernel sources; stale = a record exists
+    but for other sources."""
+    tp = ROOT / COUNTER_RECORDS
+    try:
+        ent = json.load(open(tp)).get(workload)
+    except Exception:
+        return None, False
+    if not ent:
+        return None, False
+    if ent.get("source_hash") != kernel_source_hash(workload):
+        return None, True
+    return ent, False
 
 
 def measured_traffic(workload, kernel=None):
-    """HBM bytes per launch from the PMC pass of THIS round's profile run (tools/profile.sh -> profiles/r03_pmc_traffic.json,
-    which records the commit, workload and kernel it was collected on); None when there is no such record for the workload or when
-    it was taken on another kernel than the one this run launches."""
-    tp = ROOT / "profiles" / "r03_pmc_traffic.json"
-    if not tp.exists():
-        return None, None
-    try:
-        rec = json.load(open(tp))
-    except Exception:
-        return None, None
-    ent = rec.get(workload)
-    if not ent:
-        return None, None
-    if kernel is not None and _kernel_key(ent.get("kernel")) != _kernel_key(kernel.split(" + ")[0]):
-        return None, None
-    return ent.get("hbm_bytes_per_launch"), f"profiles/r03_pmc_traffic.json ({ent.get('kernel', '?')} @ {ent.get('commit', '?')})"
+    """(HBM bytes per launch | None, where it comes from | None, stale flag)."""
+    ent, stale = counter_record(workload)
+    if ent is None or ent.get("hbm_bytes_per_launch") is None:
+        return None, None, stale
+    return ent["hbm_bytes_per_launch"], f"{COUNTER_RECORDS} ({ent.get('kernel', '?')} @ {ent.get('commit', '?')}, sources {ent.get('source_hash')})", False
+
+
+def valu_roofline(workload, avg_us, per_unit=None):
+    """FP64-VALU roofline block from the recorded SQ_INSTS_VALU of the workload's kernel (None without a current record)."""
+    ent, stale = counter_record(workload)
+    if ent is None or not ent.get("valu_wave_instructions_per_launch"):
+        return {"bound": "fp64-valu", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s", "frac": None,
+                "stale": stale, "note": "no PMC record for the current kernel sources (tools/profile.sh)"}
+    n = ent["valu_wave_instructions_per_launch"]
+    ginstr = n / avg_us / 1e3
+    blk = {"bound": "fp64-valu", "achieved": round(ginstr, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
+           "valu_wave_instructions_per_launch": n,
+           "source": f"{COUNTER_RECORDS} ({ent.get('kernel', '?')} @ {ent.get('commit', '?')}, sources {ent.get('source_hash')})"}
+    if per_unit:
+        blk[per_unit[0]] = round(n * 64 / per_unit[1], 1)
+    return blk
 
 
 def cpu_leg(a, plan, stack, icrf, diff, rows, n, H, W, with_std, corr):
@@ -277,6 +305,7 @@ def row_tile_workload(a, dev, rank, world, dist):
     if rank == 0:
         plan0 = tiles.plans[tiles.mine[0]]
         achieved = alg / n_launch / avg_us / 1e3
+        traffic, traffic_src, traffic_stale = measured_traffic("cfg4tilestd" if with_std else "cfg4tile")   # one launch = one tile
         line = {"metric": "HDR-merged Mpix/s (node)", "value": round(a.steps * H * W / elapsed / 1e6, 1), "unit": "Mpix/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 5), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -285,7 +314,8 @@ def row_tile_workload(a, dev, rank, world, dist):
                            "name": a.workload, "frames": n, "height": H, "width": W, "channels": 3, "row_tiles": n_tiles,
                            "parallelism": f"row tiles: {n_launch} per GPU, no collective on the data path", "variant": a.variant},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None, "kernel": plan0.kernels,
+                             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                             "kernel": plan0.kernels,
                              "algorithmic_bytes_per_launch": alg // n_launch, "avg_launch_us": round(avg_us, 2)},
                 "ranks": ranks,
                 "assembly_ms": round(assembly_ms, 1), "assembly_first_ms": round(assembly_first_ms, 1),
@@ -315,7 +345,8 @@ def producer_workload(a, dev, rank=0, world=1, dist=None):
         alg = int(nat.lib.hm_welford_algorithmic_bytes(K, 1, H * W * 3))
         units, unit, metric = H * W * K, "Mpix-frames/s", "Welford-folded Mpix-frames/s (mean + M2, 32 frames per launch)"
         cfg = {"workload": f"{K} uint8 4096x4096x3 frames folded into float64 mean / M2 per launch", "name": "welford"}
-        kernel, bound_note = "k_welford", "FP64 VALU from ~12 frames per launch up (DESIGN.md 4.5); frac is against the HBM roofline"
+        kernel, bound_note = "k_welford", "FP64 VALU from ~12 frames per launch up (DESIGN.md 4.4): roofline_valu is the bound that binds at 32 frames per launch"
+        valu_unit = ("instructions_per_element_frame", H * W * 3 * K)
     else:
         X = Y = 1024
         N, B = 7, 75
@@ -330,7 +361,8 @@ def producer_workload(a, dev, rank=0, world=1, dist=None):
         alg = X * Y * N * B                                                              # stack bytes x candidates
         units, unit, metric = B, "candidates/s", "ICRF-calibration energy evaluations/s (1024x1024x7 stack, 75 candidates per launch)"
         cfg = {"workload": "energy function of 75 candidate ICRFs on a 1024x1024x7 uint8 channel stack per launch", "name": "energy"}
-        kernel, bound_note = "k_energy_pixel", "FP64 VALU (DESIGN.md 4.5); frac is against the HBM roofline and not the relevant bound"
+        kernel, bound_note = "k_energy_pixel", "FP64 VALU (DESIGN.md 4.4): roofline_valu is the relevant bound, the HBM figure is not"
+        valu_unit = ("instructions_per_pixel_pair_candidate", X * Y * (N * (N - 1) // 2) * B)
     t_end = time.perf_counter() + a.prewarm_s
     while time.perf_counter() < t_end:
         launch()
@@ -362,43 +394,48 @@ def producer_workload(a, dev, rank=0, world=1, dist=None):
     if not a.no_cpu_baseline and world == 1:
         from oracle import hdr_oracle as orc
         if a.workload == "welford":
-            sample = [f[:2048].cpu().numpy() for f in clip]
+            rows_c = 2048
+            sample = [f[:rows_c].cpu().numpy() for f in clip]
             c0 = time.perf_counter()
-            orc.welford_state(sample, None, True)
+            want = orc.welford_state(sample, None, True)
             dt = time.perf_counter() - c0
-            cpu = {"value": round(2048 * W * K / dt / 1e6, 3), "unit": unit, "cores": 1, "kind": "port",
-                   "sample": f"{K} frames of 2048x{W}x3 ({dt:.1f} s), NumPy oracle, 1 thread"}
+            # parity: ONE clean fold of the same band (fresh zero state, count 0) through the timed kernel against the oracle's state
+            gm = torch.zeros((rows_c, W, 3), dtype=torch.float64, device=dev)
+            g2 = torch.zeros_like(gm)
+            engine.welford_update([f[:rows_c] for f in clip], 0, gm, g2)
+            torch.cuda.synchronize()
+
+            def rel(got, ref):
+                den = np.maximum(np.abs(ref), 1e-300)
+                return float(np.max(np.abs(got - ref) / den))
+            e_mean, e_m2 = rel(gm.cpu().numpy(), want[0]), rel(g2.cpu().numpy(), want[1])
+            cpu = {"value": round(rows_c * W * K / dt / 1e6, 3), "unit": unit, "cores": 1, "kind": "port",
+                   "sample": f"{K} frames of {rows_c}x{W}x3 ({dt:.1f} s), NumPy oracle, 1 thread; the same band folded once on the GPU is compared with it",
+                   "gpu_vs_oracle_max_rel_err": e_mean, "gpu_vs_oracle_max_rel_err_m2": e_m2, "parity_ok": bool(e_mean <= 1e-13 and e_m2 <= 1e-12)}
         else:
             reps = 10
             c0 = time.perf_counter()
-            for b in range(reps):
-                orc.energy_function(icrfs[b], dn_h, None, 5, 250, t)
+            want = [orc.energy_function(icrfs[b], dn_h, None, 5, 250, t) for b in range(reps)]
             dt = time.perf_counter() - c0
+            got = engine.linearity_energy(dn, None, t, icrfs_d, 5, 250).cpu().numpy()[:reps]
+            worst = float(np.max(np.abs(got - np.asarray(want)) / np.abs(np.asarray(want))))
             cpu = {"value": round(reps / dt, 4), "unit": unit, "cores": 1, "kind": "port",
-                   "sample": f"{reps} of the 75 candidates on the full 1024x1024x7 stack ({dt:.1f} s), NumPy oracle, 1 thread"}
+                   "sample": f"{reps} of the 75 candidates on the full 1024x1024x7 stack ({dt:.1f} s), NumPy oracle, 1 thread; the GPU energies of the same candidates are compared with it",
+                   "gpu_vs_oracle_max_rel_err": worst, "parity_ok": bool(worst <= 1e-10)}
     scale_u = 1e6 if unit.startswith("M") else 1.0
+    traffic, traffic_src, traffic_stale = measured_traffic(a.workload)
     line = {"metric": metric, "value": round(world * steps * units / elapsed / scale_u, 2), "unit": unit, "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "achieved": round(alg / avg_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(alg / avg_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2), "note": bound_note},
-            "ranks": ranks, "cpu_baseline": cpu}
+                         "frac": round(alg / avg_us / 1e3 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "kernel": kernel, "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2), "note": bound_note},
+            "roofline_valu": valu_roofline(a.workload, avg_us, valu_unit), "ranks": ranks, "cpu_baseline": cpu}
     print(json.dumps(line), flush=True)
 
 
 VALU_PEAK_GINSTR = 614.4        # FP64 vector issue rate of the part in 64-lane wave-instructions: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles
                                 # (= 78.6 TFLOP/s of FP64 FMA, half of the guide's 157.3 TFLOP/s FP32 vector peak)
-
-
-def measured_valu(workload):
-    """VALU wave-instructions per launch of the all-pairs statistics kernel, from this round's PMC pass (profiles/r03_linearity_valu.json,
-    written by tools/summarize_profile.py with the commit it was collected on); None without such a record."""
-    tp = ROOT / "profiles" / "r03_linearity_valu.json"
-    try:
-        return json.load(open(tp)).get(workload)
-    except Exception:
-        return None
 
 
 def linearity_workload(a, dev, rank=0, world=1, dist=None):
@@ -493,13 +530,8 @@ def linearity_workload(a, dev, rank=0, world=1, dist=None):
                "sample": f"rows 0..{rows_cpu - 1} of the series ({n}x{rows_cpu}x{W}x3 float64" + (" + std" if use_std else "") + f", {len(pairs)} pairs, {dt:.1f} s): "
                          "apply_thresholds + compute_difference + dimension_statistics per pair, NumPy oracle, 1 thread of " + f"{os.cpu_count()} host cores",
                "gpu_vs_oracle_max_rel_err": worst, "parity_ok": bool(worst <= 1e-10)}
-    valu = measured_valu(a.workload)
-    valu_block = None
-    if valu:
-        ginstr = valu["valu_wave_instructions_per_launch"] / avg_us / 1e3
-        valu_block = {"bound": "fp64-valu", "achieved": round(ginstr, 1), "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
-                      "instructions_per_element_pair": round(valu["valu_wave_instructions_per_launch"] * 64 / (len(pairs) * E), 1),
-                      "source": f"profiles/r03_linearity_valu.json ({valu.get('kernel', '?')} @ {valu.get('commit', '?')})"}
+    valu_block = valu_roofline(a.workload, avg_us, ("instructions_per_element_pair", len(pairs) * E))
+    traffic, traffic_src, traffic_stale = measured_traffic(a.workload)
     line = {"metric": "linearity-compared Mpix-pairs/s (process_linearity: 15 exposure pairs of 7 frames of 4096x4096x3)", "value": round(world * steps * len(pairs) * H * W / elapsed / 1e6, 1),
             "unit": "Mpix-pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -507,7 +539,8 @@ def linearity_workload(a, dev, rank=0, world=1, dist=None):
                                    + ("weighted " if use_std else "") + "statistics of the absolute and relative differences per channel", "name": a.workload, "frames": n, "pairs": len(pairs),
                        "height": H, "width": W, "channels": 3, "parallelism": "replicas only (no exchange step)"},
             "roofline": {"bound": "hbm", "achieved": round(alg / avg_us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / avg_us / 1e3 / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "kernel": "k_pairs_stats_lds", "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2),
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "kernel": "k_pairs_stats_lds",
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(avg_us, 2),
                          "note": "read-once bytes; the kernel is FP64-VALU bound (roofline_valu)"},
             "roofline_valu": valu_block, "ranks": ranks, "cpu_baseline": cpu}
     print(json.dumps(line), flush=True)
@@ -724,7 +757,7 @@ def main():
 
     if rank == 0:
         achieved = alg_bytes / avg_us / 1e3          # GB/s
-        traffic, traffic_src = measured_traffic(a.workload, plan.kernels)
+        traffic, traffic_src, traffic_stale = measured_traffic(a.workload, plan.kernels)
         mpix = world * a.steps * launches_per_step * H * W / elapsed / 1e6
         line = {
             "metric": "HDR-merged Mpix/s (node)", "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world,
@@ -742,7 +775,7 @@ def main():
                        if corr in (True, "hot") else None,
                        "parallelism": f"independent stacks x{world * max(launches_per_step, 1)} per step, no collective", "variant": a.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": plan.kernels, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_us, 2),
                          "same_stack_avg_launch_us": None if same_us is None else round(same_us, 2),

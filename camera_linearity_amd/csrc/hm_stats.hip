@@ -267,12 +267,17 @@ struct Mom {
 constexpr int kMomVals = 6;
 __device__ __forceinline__ Mom mom_zero() { return Mom{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
 
-// Per-thread accumulation, branch-free: kMomBlock elements are summed as shifted moments about K = the state's current mean
+// Per-thread accumulation, branch-free: kMomBlock (64) elements are summed as shifted moments about K = the state's current mean
 // (S0 = sum w, S1 = sum w (v - K), S2 = sum w (v - K)^2: three FMAs per element, no division), an element that NumPy's nan-functions
 // would skip enters with weight 0 and deviation 0 (selects, no branch), and the block is folded into the running (W, mean, M2) with
 // Chan's formula when the LOOP COUNTER says so (wave-uniform) - two divisions per block instead of two per element. K tracks the data
 // (until the first fold it is the first valid element), so S2 - S1^2 / S0 differences nothing large.
-constexpr int kMomBlock = 8;
+#ifndef HM_MOM_BLOCK
+#define HM_MOM_BLOCK 64      // round 4: 8 -> 64. A fold is two reciprocals, a dozen multiplies and a branch per state; the all-pairs kernel (FP64-VALU
+#endif                       // bound, two states per wave) went 2 673 -> 2 440 us with std and 1 429 -> 1 210 us without on one box (16: 2 548 / 1 305,
+                             // 32: 2 485 / 1 245, 128: 2 425 / 1 190, 256: 2 407 / 1 260; tools/gpu_r04d.sh, profiles/r04d_*). K is refreshed with the
+                             // running mean at every fold and starts as a data element, so 64 shifted terms difference nothing large.
+constexpr int kMomBlock = HM_MOM_BLOCK;
 struct MomAcc {
     Mom m;
     double K, S0, S1, S2;
@@ -683,7 +688,10 @@ template <bool STD, int UN = kPairUN>
 __device__ __forceinline__ void pair_process_any(MomAcc (&st)[2], int it, double mult, const double (&xv)[UN], const double (&xs)[UN],
                                                  const double (&yv)[UN], const double (&ys)[UN]) {
     // (without std only: with std the all-pairs kernel sits at the 128 VGPRs a 1024-thread workgroup may use and two bodies make it spill)
-    if constexpr (HM_PAIR_LEAN && !STD) {
+#ifndef HM_PAIR_LEAN_STD
+#define HM_PAIR_LEAN_STD 0
+#endif
+    if constexpr (HM_PAIR_LEAN && (!STD || HM_PAIR_LEAN_STD)) {
         if (__builtin_amdgcn_ballot_w64(st[0].haveK && st[1].haveK) == ~0ull) { pair_process<STD, UN, true>(st, it, mult, xv, xs, yv, ys); return; }
     }
     pair_process<STD, UN, false>(st, it, mult, xv, xs, yv, ys);
@@ -908,6 +916,9 @@ __global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_
             }
         }
     };
+    // a wave none of whose threads has an item (15 waves, 7 frames: items = 448 = waves 0..6) skips the loader altogether - its loads,
+    // threshold selects and LDS stores were issued for nothing before: 180 of the ~3 000 VALU wave-instructions of a workgroup iteration
+    const bool stager = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x & ~63u)) < n_items;          // wave-uniform
     MomAcc st[2] = {acc_zero(), acc_zero()};
     const uint32_t ox = static_cast<uint32_t>(pi) * 1024u + lane * 8u, oy = static_cast<uint32_t>(pj) * 1024u + lane * 8u;
     const uint32_t osx = ox + std_off, osy = oy + std_off;
@@ -932,11 +943,13 @@ __global__ __launch_bounds__(1024) void k_pairs_stats_lds(const PairsK a, int n_
     int it = 0, stage = 0;
     Fetched r;
     auto clamp = [&](int64_t b) { return (whole(b) ? b : sb) - sb0; };
-    if (whole(sb)) { fetch(0, r); stash(0, r); fetch(clamp(sb + step), r); }
+    if (whole(sb) && stager) { fetch(0, r); stash(0, r); fetch(clamp(sb + step), r); }
     while (whole(sb)) {
         const int nxt = stage == 2 ? 0 : stage + 1;
-        stash(nxt, r);
-        fetch(clamp(sb + 2 * step), r);
+        if (stager) {
+            stash(nxt, r);
+            fetch(clamp(sb + 2 * step), r);
+        }
         __syncthreads();
         compute(stage, it);
         ++it; sb += step; stage = nxt;

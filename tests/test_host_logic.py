@@ -394,3 +394,27 @@ def test_bench_does_not_self_launch_under_a_launcher():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_bench_counter_records_go_stale_with_the_kernel_source(tmp_path, monkeypatch):
+    """bench.py prints a PMC record (roofline.traffic, roofline_valu) only while the hash stored with it is the hash of the kernel's
+    source files in this tree; a record collected on other sources reads as traffic None + traffic_stale True."""
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    h = bench.kernel_source_hash("cfg2")
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and h == bench.kernel_source_hash("cfg3flat") and h != bench.kernel_source_hash("linearitystd")
+    assert bench.kernel_source_hash("welford") != bench.kernel_source_hash("energy")
+    rec = tmp_path / "rec.json"
+    monkeypatch.setattr(bench, "COUNTER_RECORDS", str(rec))
+    assert bench.measured_traffic("cfg2") == (None, None, False)                   # no record at all
+    json.dump({"cfg2": {"hbm_bytes_per_launch": 755e6, "kernel": "k", "commit": "abc", "source_hash": h},
+               "cfg3": {"hbm_bytes_per_launch": 4.9e9, "kernel": "k", "commit": "abc", "source_hash": "0" * 16},
+               "linearitystd": {"valu_wave_instructions_per_launch": 1.0e9, "kernel": "k", "commit": "abc", "source_hash": bench.kernel_source_hash("linearity")}},
+              open(rec, "w"))
+    t, src, stale = bench.measured_traffic("cfg2")
+    assert t == 755e6 and "abc" in src and stale is False
+    assert bench.measured_traffic("cfg3") == (None, None, True)                    # collected on other sources
+    blk = bench.valu_roofline("linearitystd", 2000.0, ("instructions_per_element_pair", 64e6))
+    assert blk["frac"] == round(1.0e9 / 2000.0 / 1e3 / bench.VALU_PEAK_GINSTR, 4) and blk["instructions_per_element_pair"] == 1000.0
+    assert bench.valu_roofline("welford", 100.0)["frac"] is None

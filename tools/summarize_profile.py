@@ -4,8 +4,8 @@ per-kernel time from --kernel-trace --stats, PMC counters per launch of the merg
 traffic corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and on gfx950
 reads exactly 1/2 of a wide coalesced streaming read's bytes -> doubled; WRITE_SIZE in KiB, exact).
 usage: summarize_profile.py <prof dir> <tag> [kernel substring] [algorithmic bytes] [workload] [commit]
-With a workload name it also records the measured HBM bytes per launch in profiles/<round>_pmc_traffic.json (round = $HM_ROUND, default r03; what bench.py
-prints as roofline.traffic, with the commit the counters were collected on).
+With a workload name it also records the measured HBM bytes (and VALU wave-instructions) per launch in profiles/r04_pmc_counters.json - what bench.py
+prints as roofline.traffic / roofline_valu - with the commit and the hash of the kernel's source files the counters were collected on.
 DATA-DEPENDENT KERNELS: pass the dominant kernel's name substring; counters are averaged over its launches only.
 A workload that is several kernels per step (config 3: streaming merge + hot-pixel pass) passes "nameA+nameB": the step time is the
 sum of the kernels' average durations and the counters are summed over them (each averaged over its own launches)."""
@@ -92,19 +92,21 @@ with open(f"profiles/{tag}_rocprof_summary.md", "w") as f:
                 f"= {t['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch = {t['ratio_to_algorithmic']:.3f} x algorithmic ({alg / 1e6:.1f} MB)\n")
     if d:
         f.write("\n## Derived\n\n" + "\n".join(f"- {k}: {v:.4g}" for k, v in d.items()) + "\n")
-if len(sys.argv) > 5 and "traffic" in out:
+if len(sys.argv) > 5:
+    # profiles/r04_pmc_counters.json: what bench.py prints as roofline.traffic / roofline_valu - keyed by workload, stamped with the
+    # commit AND the hash of the kernel's source files (bench.kernel_source_hash), so a record goes stale with the first edit of its kernel
     import pathlib
-    tp = pathlib.Path(f"profiles/{os.environ.get('HM_ROUND', 'r03')}_pmc_traffic.json")
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    import bench
+    tp = pathlib.Path(bench.COUNTER_RECORDS)
     rec = json.load(open(tp)) if tp.exists() else {}
-    rec[sys.argv[5]] = {"hbm_bytes_per_launch": out["traffic"]["hbm_bytes_per_launch"], "ratio_to_algorithmic": out["traffic"]["ratio_to_algorithmic"],
-                        "kernel": merge["name"], "commit": sys.argv[6] if len(sys.argv) > 6 else "?", "source": f"profiles/{tag}_rocprof_summary.json"}
-    json.dump(rec, open(tp, "w"), indent=1)
-if len(sys.argv) > 5 and "pairs_stats" in kname and "SQ_INSTS_VALU" in counters:
-    import pathlib
-    tp = pathlib.Path(f"profiles/{os.environ.get('HM_ROUND', 'r03')}_linearity_valu.json")
-    rec = json.load(open(tp)) if tp.exists() else {}
-    rec[sys.argv[5]] = {"valu_wave_instructions_per_launch": counters["SQ_INSTS_VALU"], "kernel": merge["name"], "avg_us_under_profiler": merge["avg_us"],
-                        "valu_busy_frac": (counters.get("SQ_ACTIVE_INST_VALU", 0) / counters["SQ_WAVE_CYCLES"]) if counters.get("SQ_WAVE_CYCLES") else None,
-                        "commit": sys.argv[6] if len(sys.argv) > 6 else "?", "source": f"profiles/{tag}_rocprof_summary.json"}
+    ent = {"kernel": merge["name"], "avg_us_under_profiler": merge["avg_us"], "commit": sys.argv[6] if len(sys.argv) > 6 else "?",
+           "source_hash": bench.kernel_source_hash(sys.argv[5]), "source": f"profiles/{tag}_rocprof_summary.json"}
+    if "traffic" in out:
+        ent.update(hbm_bytes_per_launch=out["traffic"]["hbm_bytes_per_launch"], ratio_to_algorithmic=out["traffic"]["ratio_to_algorithmic"])
+    if "SQ_INSTS_VALU" in counters:
+        ent.update(valu_wave_instructions_per_launch=counters["SQ_INSTS_VALU"],
+                   valu_busy_frac=(counters.get("SQ_ACTIVE_INST_VALU", 0) / counters["SQ_WAVE_CYCLES"]) if counters.get("SQ_WAVE_CYCLES") else None)
+    rec[sys.argv[5]] = ent
     json.dump(rec, open(tp, "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("merge_kernel", "launch", "counters_per_launch", "traffic", "derived", "roofline") if k in out}, indent=1))
