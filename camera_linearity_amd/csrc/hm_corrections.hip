@@ -343,7 +343,7 @@ static int hot_filter_common(const T* x, const uint8_t* map_u8, const double* ma
     // 12 workgroups per CU and every wave the same number of spans: 25.3-25.6 us for a 4096 x 4096 x 3 uint8 frame (0.74-0.75 of 8 TB/s, the box's
     // copy rate) against 27.3 us with 8 (12 288 spans on 8 192 waves) - profiles/r03_hot_filter_grid.log
     if (n_spans > 0)
-        hipLaunchKernelGGL(k_hot_filter_burst<T>, dim3(balanced_wave_grid(n_spans, 4, getenv("HM_TUNE_HOT_WG") ? atoi(getenv("HM_TUNE_HOT_WG")) : 12)), dim3(256), 0, as_stream(stream), x, map_u8, min_dn, k, out, H, W, C, n_spans);
+        hipLaunchKernelGGL(k_hot_filter_burst<T>, dim3(balanced_wave_grid(n_spans, 4, 12)), dim3(256), 0, as_stream(stream), x, map_u8, min_dn, k, out, H, W, C, n_spans);
     const int64_t done = n_spans * span_elems;
     if (done < n) {
         const int64_t rest = n - done;

@@ -27,8 +27,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
+
+#ifndef HM_TUNE_NF
+#define HM_TUNE_NF 0      /* build with -DHM_TUNE_NF=7 to get the variant matrix for N = 7 */
+#endif
 
 namespace hm {
 
@@ -973,6 +978,9 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
     reset_hot_counters(a);
     static_assert(CH == 3 || (CH == 1 && STD && !SUMW), "monochrome: the std instantiations (with or without the flat field) only");
     constexpr int C = CH;
+    // frames up to which pass 2 keeps its per-frame state pinned / its std loads issued early (flat-field instantiations). With the
+    // sum-of-weights output on top, N = 8 needed 168 VGPRs + 20 bytes of scratch per lane: that one shape takes the N > 8 form (152 VGPRs)
+    constexpr int PIN_NF = SUMW ? HM_PIN_NF - 1 : HM_PIN_NF;
     constexpr uint32_t GROUP = U * kSub;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lane2 = lane * 2u;
@@ -1119,7 +1127,7 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
                 const char* t_gd = lds + 16 * 256;
                 // HM_STD_EARLY (flat-field instantiations): all NF float64 std loads of the sub-unit are issued here, ahead of pass 1's
                 // gathers (4 VGPRs per frame: stacks of up to HM_PIN_NF frames only), instead of HM_STD_FB frames at a time inside pass 2
-                constexpr bool EARLY = HM_STD_EARLY && FLAT && NF <= HM_PIN_NF;
+                constexpr bool EARLY = HM_STD_EARLY && FLAT && NF <= PIN_NF;
                 f64x2 sd_early[EARLY ? NF : 1];
                 if constexpr (EARLY) {
 #pragma unroll
@@ -1159,11 +1167,11 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
                     if constexpr (EARLY) sdv = sd_early[i];
                     else {
                         const double* sp = a.sd[i] + a.in_off + sbase;                           // scalar base
-                        if (NF > HM_PIN_NF || !FLAT) asm volatile("" : "+s"(sp));     // keep base + 32-bit lane offset addressing (no per-frame VGPR address pairs)
+                        if (NF > PIN_NF || !FLAT) asm volatile("" : "+s"(sp));     // keep base + 32-bit lane offset addressing (no per-frame VGPR address pairs)
                         sdv = ld_f64x2_global(sp, lane16);
                     }
                     uint32_t packed = cur[i][s];
-                    if (NF > HM_PIN_NF || !FLAT) HM_PIN(packed);                  // re-extract the DNs here instead of keeping pass 1's indices alive
+                    if (NF > PIN_NF || !FLAT) HM_PIN(packed);                  // re-extract the DNs here instead of keeping pass 1's indices alive
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const uint32_t dn = j == 0 ? (packed & 255u) : (packed >> 8);
@@ -1215,13 +1223,19 @@ __device__ __forceinline__ void merge_u8_fast_body(const MergeK& a) {
 #ifndef HM_STD_WAVES
 #define HM_STD_WAVES 3
 #endif
+// Round 4: the flat-field instantiations (two more streams, the early std loads, the epilogue's operands) take a target of 2: config 3's
+// std + flat stack 808-821 -> 790-792 us on one box, two runs each (tools/gpu_r04f.sh, profiles/r04f_*); without a flat field 2 costs 7 %.
+#ifndef HM_STD_WAVES_FLAT
+#define HM_STD_WAVES_FLAT 2
+#endif
 template <int NF, int U, int TAB, bool STD, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK>
 __global__ __launch_bounds__(BLOCK) HM_WAVES_ATTR void merge_u8_fast(const MergeK a) {
     static_assert(!STD, "std instantiations go through merge_u8_fast_std");
     merge_u8_fast_body<NF, U, TAB, false, PREFETCH, FLAT, SUMW, BLOCK>(a);
 }
 template <int NF, int U, int TAB, bool PREFETCH, bool FLAT, bool SUMW, int BLOCK, int CH = 3>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(HM_STD_WAVES, HM_STD_WAVES))) void merge_u8_fast_std(const MergeK a) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FLAT ? HM_STD_WAVES_FLAT : HM_STD_WAVES, FLAT ? HM_STD_WAVES_FLAT : HM_STD_WAVES)))
+void merge_u8_fast_std(const MergeK a) {
     merge_u8_fast_body<NF, U, TAB, true, PREFETCH, FLAT, SUMW, BLOCK, CH>(a);
 }
 
@@ -1998,10 +2012,18 @@ static bool describe_only(const char* fmt, int a = 0, int b = 0, int c = 0, int 
     return true;
 }
 
-// experiment knobs read from the environment (tools/ A/B scripts; unset in production): 0 = not set
-static int tune_env(const char* name) {
+// experiment knobs of the tools/ A/B scripts, read from the environment in TUNING BUILDS only (-DHM_TUNE_NF=<N> or -DHM_TUNE_ENV): the shipped
+// library never calls getenv. 0 = not set; values are clamped to [lo, hi] (a bmax above 64 or a per-CU count of 0 must not reach a launch).
+static int tune_env(const char* name, int lo, int hi) {
+#if HM_TUNE_NF != 0 || defined(HM_TUNE_ENV)
     const char* v = getenv(name);
-    return v ? atoi(v) : 0;
+    const int e = v ? atoi(v) : 0;
+    if (e == 0) return 0;
+    return e < lo ? lo : (e > hi ? hi : e);
+#else
+    (void)name; (void)lo; (void)hi;
+    return 0;
+#endif
 }
 
 static int g_cu_count = 0;
@@ -2058,16 +2080,12 @@ static int launch_one(const MergeK& k, hipStream_t st) {
                               : (STD ? "merge_u8_fast_std<N=%d,U=%d,flat=%d,sum_w=%d>" : "merge_u8_fast<N=%d,U=%d,flat=%d,sum_w=%d>"), NF, U, FLAT, SUMW)) return HM_OK;
     int per_cu = 2048 / BLOCK;                       // 32 waves per CU
     if (kMaxLds / lds < per_cu) per_cu = kMaxLds / lds;
-    if (const int e = tune_env("HM_TUNE_WG_PER_CU")) per_cu = e;
+    if (const int e = tune_env("HM_TUNE_WG_PER_CU", 1, 64)) per_cu = e;
     const int64_t groups = k.n_elems / (U * static_cast<int>(kSub));
     const unsigned grid = stream_grid(groups, BLOCK / 64, per_cu);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, st, k);
     return launch_status();
 }
-
-#ifndef HM_TUNE_NF
-#define HM_TUNE_NF 0      /* build with -DHM_TUNE_NF=7 to get the variant matrix for N = 7 */
-#endif
 
 // the val-only, no-extras configuration runs merge_u8_val3 unless a variant asks for the older merge_u8_fast (A/B runs).
 // variant 7UPM (tuning builds, N == HM_TUNE_NF only) selects merge_u8_val3<NF, U, PF, MAP>; 0 = the production choice.
@@ -2357,22 +2375,32 @@ static int launch_hot_queue(const MergeK& k, bool f64in, bool with_std, uint32_t
     const void* fn;
     if (f64in) fn = with_std ? reinterpret_cast<const void*>(merge_patch_hot<true, true>) : reinterpret_cast<const void*>(merge_patch_hot<true, false>);
     else       fn = with_std ? reinterpret_cast<const void*>(merge_patch_hot<false, true>) : reinterpret_cast<const void*>(merge_patch_hot<false, false>);
-    // (the query costs a few microseconds of host time: remembered per kernel and LDS size; a race between threads only repeats it)
-    static struct { const void* fn; int keep, per_cu; } seen[8];
+    // (the query costs a few microseconds of host time: remembered per kernel, LDS size and device, under a mutex - hm_merge may be called
+    // from several host threads)
+    static struct { const void* fn; int keep, dev, per_cu; } seen[16];
     static int n_seen = 0;
-    int per_cu = 0;
-    for (int i = 0; i < n_seen && i < 8; ++i)
-        if (seen[i].fn == fn && seen[i].keep == keep) per_cu = seen[i].per_cu;
-    if (per_cu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, static_cast<size_t>(keep)) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (per_cu > 8) per_cu = 8;
-        const int slot = n_seen < 8 ? n_seen++ : 7;
-        seen[slot].fn = fn; seen[slot].keep = keep; seen[slot].per_cu = per_cu;
+    static std::mutex seen_lock;
+    int per_cu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> hold(seen_lock);
+        for (int i = 0; i < n_seen; ++i)
+            if (seen[i].fn == fn && seen[i].keep == keep && seen[i].dev == dev) per_cu = seen[i].per_cu;
     }
-    if (const int e = tune_env("HM_TUNE_PATCH_WG_PER_CU")) per_cu = e;
+    if (per_cu == 0) {
+        // (gfx950 has 160 KB of LDS per workgroup; the kernel's 36 KB of tables + up to 32 KB of kept float64 frames fit. Should a device
+        // report that not even one workgroup fits, -1 is remembered and the workspace-free pass runs instead - never a failing launch.)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, static_cast<size_t>(keep)) != hipSuccess) { (void)hipGetLastError(); per_cu = 2; }
+        if (per_cu < 1) per_cu = -1;
+        if (per_cu > 8) per_cu = 8;
+        std::lock_guard<std::mutex> hold(seen_lock);
+        if (n_seen < 16) { seen[n_seen].fn = fn; seen[n_seen].keep = keep; seen[n_seen].dev = dev; seen[n_seen].per_cu = per_cu; ++n_seen; }
+    }
+    if (per_cu < 0) return launch_fixup(k, f64in, with_std, st);
+    if (const int e = tune_env("HM_TUNE_PATCH_WG_PER_CU", 1, 16)) per_cu = e;
     const unsigned grid = stream_grid(k.n_elems, 256, per_cu);
     uint32_t bmax = 64;
-    if (const int e = tune_env("HM_TUNE_PATCH_BMAX")) bmax = static_cast<uint32_t>(e);
+    if (const int e = tune_env("HM_TUNE_PATCH_BMAX", 1, 64)) bmax = static_cast<uint32_t>(e);
 #define HM_PATCH(K, F, S) hipLaunchKernelGGL((K<F, S>), dim3(grid), dim3(256), keep, st, k, static_cast<const uint32_t*>(ws), bmax)
 #define HM_PATCH4(K) { if (f64in) { if (with_std) HM_PATCH(K, true, true); else HM_PATCH(K, true, false); } \
                        else       { if (with_std) HM_PATCH(K, false, true); else HM_PATCH(K, false, false); } }

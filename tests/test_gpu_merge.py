@@ -397,7 +397,7 @@ def test_hot_pixel_queue_smallest_workspace(eng):
     assert torch.equal(plan.outputs["val"], old.outputs["val"]) and torch.equal(plan.outputs["std"], old.outputs["std"])
 
 
-@pytest.mark.parametrize("n", [7, 17, 20, 32])
+@pytest.mark.parametrize("n", [7, 8, 17, 20, 32])          # (8 + std + flat + sum of weights: the instantiation that spilled 20 B/lane in round 3)
 @pytest.mark.parametrize("with_std", [False, True])
 def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std, n):
     """variant < 0 forces merge_generic; it must reproduce merge_u8_fast (N <= 16) and merge_u8_loop (run-time frame
