@@ -215,6 +215,17 @@ def cpu_leg(a, plan, stack, icrf, diff, rows, n, H, W, with_std, corr):
            "gpu_vs_oracle_max_rel_err": rv, "gpu_vs_oracle_max_rel_err_std": rs,
            "parity_ok": bool(rv <= tol_v and (rs is None or rs <= 1e-9))}
     threads = min(16, os.cpu_count() or 1)          # the one-GPU box's CPU share
+    if not corr and "f64" not in a.workload:
+        # the package's own explicit host backend (Measurand(use_cupy=False): libhdrmerge_host.so, C++ / OpenMP) on the same rows - a product
+        # path, reported beside the oracle's number and checked against the same oracle output
+        from camera_linearity_amd.measurand import _HOST_ENGINE as heng
+        hf = [torch.from_numpy(x) for x in fh]
+        hs = None if sh is None else [torch.from_numpy(x) for x in sh]
+        t1 = time.perf_counter()
+        hout = heng.merge(hf, stack["t"], icrf, diff if with_std else None, hs)
+        dt_h = time.perf_counter() - t1
+        cpu["host_backend"] = {"value": round(band * W / dt_h / 1e6, 4), "unit": "Mpix/s", "cores": threads, "kind": "product host build (libhdrmerge_host.so, OpenMP)",
+                               "max_rel_err_vs_oracle": max_rel(hout["val"].numpy(), ref["val"]), "sample": f"same rows ({dt_h:.2f} s)"}
     if threads > 1 and not corr:
         dt_t = cpu_baseline_threaded(stack["frames"], stack["t"], icrf, diff if with_std else None, stack["stds"], rows, threads)
         cpu["threaded"] = {"value": round(rows * W / dt_t / 1e6, 4), "unit": "Mpix/s", "cores": threads,

@@ -11,6 +11,8 @@ import ctypes as C
 import os
 import pathlib
 
+import threading
+
 import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 
 _HERE = pathlib.Path(__file__).resolve().parent
@@ -152,10 +154,65 @@ def _load():
     return lib
 
 
-lib = _load()
 HM_ABI_VERSION = 2
-if lib.hm_version() != HM_ABI_VERSION:
-    raise ImportError(f"libhdrmerge ABI version {lib.hm_version()} != {HM_ABI_VERSION} expected by this package")
+hip_lib = _load()
+if hip_lib.hm_version() != HM_ABI_VERSION:
+    raise ImportError(f"libhdrmerge ABI version {hip_lib.hm_version()} != {HM_ABI_VERSION} expected by this package")
+
+# ---- the HOST build of the same ABI (csrc_host/hm_host.cpp -> lib/libhdrmerge_host.so): the reference's NumPy slot, Measurand(use_cupy=False).
+# Loaded on first use and only through host_mode(); the HIP path never reaches it (engine._require_cuda rejects host tensors outside host_mode).
+HOST_LIB_PATH = pathlib.Path(os.environ.get("HDRMERGE_HOST_LIB", _HERE / "lib" / "libhdrmerge_host.so"))
+HOST_ONLY_MISSING = ("hm_debug_clock_probe", "hm_debug_copy_probe", "hm_debug_stride_probe", "hm_tiff_lzw_decode", "hm_tiff_packbits_decode")
+_host_lib = None
+_mode = threading.local()
+
+
+def host_lib():
+    global _host_lib
+    if _host_lib is None:
+        if not HOST_LIB_PATH.exists():
+            raise ImportError(f"libhdrmerge_host.so not found at {HOST_LIB_PATH}: build it with `make -C camera_linearity_amd/csrc host` (g++)")
+        h = _Lib(C.CDLL(str(HOST_LIB_PATH)))
+        for name, (res, args) in _SIGNATURES.items():
+            if name not in HOST_ONLY_MISSING:
+                h._bind(name, res, args)
+        if h.hm_version() != HM_ABI_VERSION:
+            raise ImportError(f"libhdrmerge_host ABI version {h.hm_version()} != {HM_ABI_VERSION}")
+        if "OMP_NUM_THREADS" not in os.environ:            # OpenMP would start one thread per core of the machine: keep to a one-GPU box's CPU share
+            try:
+                C.CDLL("libgomp.so.1").omp_set_num_threads(min(16, os.cpu_count() or 1))
+            except OSError:
+                pass
+        _host_lib = h
+    return _host_lib
+
+
+def in_host_mode() -> bool:
+    return getattr(_mode, "depth", 0) > 0
+
+
+class host_mode:
+    """Context manager: inside it `lib` is the host build and engine functions take HOST tensors (and only those). Entered by
+    HostMeasurand / host ImageSets around every engine call; never entered by the HIP backend."""
+
+    def __enter__(self):
+        host_lib()
+        _mode.depth = getattr(_mode, "depth", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _mode.depth -= 1
+        return False
+
+
+class _Dispatch:
+    """`lib`: the HIP library, or - inside host_mode() - the host library. `calls` is the active library's call counter."""
+
+    def __getattr__(self, name):
+        return getattr(_host_lib if in_host_mode() else hip_lib, name)
+
+
+lib = _Dispatch()
 
 
 def strerror(code: int) -> str:

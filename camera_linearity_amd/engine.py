@@ -25,11 +25,30 @@ _U8 = torch.uint8
 # small helpers
 # ---------------------------------------------------------------------------------------------
 def _require_cuda(t: torch.Tensor, name: str) -> None:
+    """The operand lives where the active library computes: in HBM for the HIP backend - or, inside nat.host_mode() (the explicit
+    host backend, Measurand(use_cupy=False)), in host memory. The HIP backend never takes host tensors: there is no CPU fallback."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(t)} instead.")
+    if nat.in_host_mode():
+        if t.is_cuda:
+            raise RuntimeError(f"{name} lives on {t.device}; the host backend computes on host tensors")
+        return
     if not t.is_cuda:
         raise RuntimeError(f"{name} lives on {t.device}; the HIP backend only computes on device tensors "
                            "(there is no CPU fallback)")
+
+
+class _NoDevice:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _on(device):
+    """torch.cuda.device(device) for the HIP backend, nothing for host tensors."""
+    return _NoDevice() if torch.device(device).type != "cuda" else torch.cuda.device(device)
 
 
 def _dev_f64(x, device) -> torch.Tensor:
@@ -77,8 +96,8 @@ def dark_min_dn(scale: float, threshold: float) -> int:
     return int(hot[0]) if hot.size else BITS
 
 
-def _stream(device) -> int:
-    return nat.current_stream_ptr(device)
+def _stream(device):
+    return None if torch.device(device).type != "cuda" else nat.current_stream_ptr(device)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -89,7 +108,7 @@ def u8_to_unit(dn: torch.Tensor) -> torch.Tensor:
     _require_cuda(dn, "dn")
     dn = dn.contiguous()
     out = torch.empty(dn.shape, dtype=_F64, device=dn.device)
-    with torch.cuda.device(dn.device):
+    with _on(dn.device):
         nat.check(nat.lib.hm_u8_to_unit_f64(dn.data_ptr(), out.data_ptr(), dn.numel(), _stream(dn.device)), "hm_u8_to_unit_f64")
     return out
 
@@ -100,7 +119,7 @@ def gaussian_weight(val: torch.Tensor):
     val = val.contiguous()
     w = torch.empty(val.shape, dtype=_F64, device=val.device)
     dw = torch.empty(val.shape, dtype=_F64, device=val.device)
-    with torch.cuda.device(val.device):
+    with _on(val.device):
         if val.dtype == _U8:
             wl, dwl = weight_luts(val.device)
             rc = nat.lib.hm_gaussian_weight_u8(val.data_ptr(), wl.data_ptr(), dwl.data_ptr(), w.data_ptr(), dw.data_ptr(),
@@ -138,7 +157,7 @@ def linearize(val: torch.Tensor, std: Optional[torch.Tensor], icrf, icrf_diff=No
     out_val = torch.empty(val.shape, dtype=_F64, device=dev)
     out_std = torch.empty(val.shape, dtype=_F64, device=dev) if use_std else None
     idx = None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if val.dtype == _U8:
             rc = nat.lib.hm_linearize_u8(val.data_ptr(), nat.ptr(std) if use_std else None, icrf_t.data_ptr(), nat.ptr(diff_t),
                                          out_val.data_ptr(), nat.ptr(out_std), val.numel(), C_, lut_stride, _stream(dev))
@@ -180,7 +199,7 @@ def hot_pixel_filter(x: torch.Tensor, dark_map: torch.Tensor, threshold: float, 
     fn = {_U8: nat.lib.hm_hot_pixel_filter_u8, _F64: nat.lib.hm_hot_pixel_filter_f64}.get(x.dtype)
     if fn is None:
         raise TypeError("hot_pixel_filter expects uint8 or float64 data")
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         nat.check(fn(x.data_ptr(), mu8, mf64, int(min_dn), float(threshold), int(median_k), out.data_ptr(), H, W, Cc,
                      _stream(x.device)), "hm_hot_pixel_filter")
     return out
@@ -207,7 +226,7 @@ def roi_mean(img: torch.Tensor, x0: int, x1: int, y0: int, y1: int) -> torch.Ten
     fn = {_U8: nat.lib.hm_roi_mean_u8, _F64: nat.lib.hm_roi_mean_f64}.get(img.dtype)
     if fn is None:
         raise TypeError("roi_mean expects uint8 or float64")
-    with torch.cuda.device(img.device):
+    with _on(img.device):
         nat.check(fn(img.data_ptr(), H, W, Cc, x0, x1, y0, y1, out.data_ptr(), ws.data_ptr(), _stream(img.device)), "hm_roi_mean")
     return out
 
@@ -223,7 +242,7 @@ def normalize_by_map(val: torch.Tensor, std: Optional[torch.Tensor], flat: torch
     s = (C.c_double * nat.HM_MAX_CHANNELS)(*[float(x) for x in (ff_std_mean if ff_std_mean is not None else [0.0] * Cc)])
     out_val = torch.empty_like(val)
     out_std = torch.empty_like(val) if std is not None else None
-    with torch.cuda.device(val.device):
+    with _on(val.device):
         nat.check(nat.lib.hm_normalize_by_map(
             val.data_ptr(), nat.ptr(std.contiguous()) if std is not None else None,
             flat.data_ptr() if flat.dtype == _U8 else None, flat.data_ptr() if flat.dtype == _F64 else None,
@@ -247,27 +266,33 @@ class MergePlan:
         self.device = torch.device(device)
         self.outputs = outputs
         self._ref = C.byref(args)
+        self.host = self.device.type != "cuda"             # a plan of the host backend (built inside nat.host_mode())
 
     def launch(self, stream: Optional[int] = None) -> None:
+        if self.host:
+            with nat.host_mode():
+                nat.check(nat.lib.hm_merge(self._ref, None), "hm_merge")
+            return
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         if torch.cuda.current_device() == self.device.index:
             rc = nat.lib.hm_merge(self._ref, stream)
         else:
-            with torch.cuda.device(self.device):
+            with _on(self.device):
                 rc = nat.lib.hm_merge(self._ref, stream)
         if rc:
             nat.check(rc, "hm_merge")
 
     @property
     def algorithmic_bytes(self) -> int:
-        return int(nat.lib.hm_merge_algorithmic_bytes(C.byref(self.args)))
+        return int(nat.hip_lib.hm_merge_algorithmic_bytes(C.byref(self.args)))
 
     @property
     def kernels(self) -> str:
         """Names of the kernels launch() dispatches to, in launch order (hm_merge_describe: the library's own dispatch, dry)."""
         buf = C.create_string_buffer(512)
-        nat.check(nat.lib.hm_merge_describe(self._ref, buf, 512), "hm_merge_describe")
+        lib = nat.host_lib() if self.host else nat.hip_lib
+        nat.check(lib.hm_merge_describe(self._ref, buf, 512), "hm_merge_describe")
         return buf.value.decode()
 
 
@@ -483,7 +508,7 @@ def elementwise_binary(op: int, x1: torch.Tensor, s1, x2: torch.Tensor, s2):
     sh = (C.c_int64 * nd)(*shape)
     st1 = (C.c_int64 * nd)(*_bcast_strides(x1, shape))
     st2 = (C.c_int64 * nd)(*_bcast_strides(x2, shape))
-    with torch.cuda.device(x1.device):
+    with _on(x1.device):
         nat.check(nat.lib.hm_binary_op(op, x1.data_ptr(), nat.ptr(s1), x2.data_ptr(), nat.ptr(s2), out.data_ptr(),
                                        nat.ptr(out_std), nd, sh, st1, st2, _stream(x1.device)), "hm_binary_op")
     return out, out_std
@@ -496,7 +521,7 @@ def pow_scalar(x: torch.Tensor, s: Optional[torch.Tensor], exponent: float):
     s = None if s is None else s.to(_F64).contiguous()
     out = torch.empty_like(x)
     out_s = None if s is None else torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         nat.check(nat.lib.hm_pow_scalar(x.data_ptr(), nat.ptr(s), float(exponent), out.data_ptr(), nat.ptr(out_s), x.numel(),
                                         _stream(x.device)), "hm_pow_scalar")
     return out, out_s
@@ -509,7 +534,7 @@ def elementwise_unary(op: int, x: torch.Tensor, s):
         s = s.to(_F64).contiguous()
     out = torch.empty_like(x)
     out_std = torch.empty_like(x) if s is not None else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         nat.check(nat.lib.hm_unary_op(op, x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_std), x.numel(),
                                       _stream(x.device)), "hm_unary_op")
     return out, out_std
@@ -541,7 +566,7 @@ def take_axis(x: torch.Tensor, s: Optional[torch.Tensor], indices: Sequence[int]
         raise IndexError(f"index out of bounds for axis of size {axis_len}")
     out = torch.empty(out_shape, dtype=_F64, device=x.device)
     out_s = None if s is None else torch.empty(out_shape, dtype=_F64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if len(idx) <= HM_TAKE_MAX:
             arr = (C.c_int64 * len(idx))(*idx)
             nat.check(nat.lib.hm_take_axis(x.data_ptr(), nat.ptr(s), out.data_ptr(), nat.ptr(out_s), outer, axis_len, inner,
@@ -572,7 +597,7 @@ def apply_thresholds_(val: torch.Tensor, std: Optional[torch.Tensor], lower: Seq
     Cc = val.shape[-1]
     lo = (C.c_double * Cc)(*[float(x) for x in lower])
     hi = (C.c_double * Cc)(*[float(x) for x in upper])
-    with torch.cuda.device(val.device):
+    with _on(val.device):
         nat.check(nat.lib.hm_apply_thresholds(val.data_ptr(), nat.ptr(std), lo, hi, val.numel(), Cc, _stream(val.device)),
                   "hm_apply_thresholds")
 
@@ -607,7 +632,7 @@ def compute_difference(x, sx, y, sy, multiplier: float):
         with_std = sx is not None or sy is not None
         mk = lambda on: torch.empty(shape, dtype=_F64, device=x.device) if on else None      # noqa: E731
         ad, rd, ads, rds = mk(True), mk(True), mk(with_std), mk(with_std)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             nat.check(nat.lib.hm_compute_difference_bcast(x.data_ptr(), nat.ptr(sx), y.data_ptr(), nat.ptr(sy), float(multiplier), ad.data_ptr(),
                                                           nat.ptr(ads), rd.data_ptr(), nat.ptr(rds), len(shape), sh, st1, st2, _stream(x.device)),
                       "hm_compute_difference_bcast")
@@ -618,7 +643,7 @@ def compute_difference(x, sx, y, sy, multiplier: float):
     ad, rd = torch.empty_like(x), torch.empty_like(x)
     ads = torch.empty_like(x) if with_std else None
     rds = torch.empty_like(x) if with_std else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         nat.check(nat.lib.hm_compute_difference(x.data_ptr(), nat.ptr(sx), y.data_ptr(), nat.ptr(sy), float(multiplier),
                                                 ad.data_ptr(), nat.ptr(ads), rd.data_ptr(), nat.ptr(rds), x.numel(),
                                                 _stream(x.device)), "hm_compute_difference")
@@ -636,14 +661,14 @@ def interpolate(x0, s0, x1, s1, y0: float, y1: float, y: float):
         shape, sh, st0, st1 = _bcast_setup(x0, s0, x1, s1)
         out = torch.empty(shape, dtype=_F64, device=x0.device)
         out_std = torch.empty(shape, dtype=_F64, device=x0.device) if (s0 is not None or s1 is not None) else None
-        with torch.cuda.device(x0.device):
+        with _on(x0.device):
             nat.check(nat.lib.hm_interpolate_bcast(x0.data_ptr(), nat.ptr(s0), x1.data_ptr(), nat.ptr(s1), float(y0), float(y1), float(y),
                                                    out.data_ptr(), nat.ptr(out_std), len(shape), sh, st0, st1, _stream(x0.device)),
                       "hm_interpolate_bcast")
         return out, out_std
     out = torch.empty_like(x0)
     out_std = torch.empty_like(x0) if (s0 is not None or s1 is not None) else None
-    with torch.cuda.device(x0.device):
+    with _on(x0.device):
         nat.check(nat.lib.hm_interpolate(x0.data_ptr(), nat.ptr(s0), x1.data_ptr(), nat.ptr(s1), float(y0), float(y1), float(y),
                                          out.data_ptr(), nat.ptr(out_std), x0.numel(), _stream(x0.device)), "hm_interpolate")
     return out, out_std
@@ -657,7 +682,7 @@ def channel_statistics(val: torch.Tensor, std: Optional[torch.Tensor]):
     Cc = val.shape[-1]
     out = torch.empty(3 * Cc, dtype=_F64, device=val.device)
     ws = torch.empty(nat.lib.hm_channel_statistics_workspace_bytes() // 8, dtype=_F64, device=val.device)
-    with torch.cuda.device(val.device):
+    with _on(val.device):
         nat.check(nat.lib.hm_channel_statistics(val.data_ptr(), nat.ptr(std), val.numel(), Cc, out.data_ptr(), ws.data_ptr(),
                                                 _stream(val.device)), "hm_channel_statistics")
     return {"mean": out[:Cc], "std": out[Cc:2 * Cc], "error": out[2 * Cc:] if std is not None else None}
@@ -700,7 +725,7 @@ def axis_statistics(val: torch.Tensor, std: Optional[torch.Tensor], axis):
     err = torch.empty(out_shape, dtype=_F64, device=dev) if std is not None else None
     ws_b = int(nat.lib.hm_axis_statistics_workspace_bytes(outer, A, inner))
     ws = torch.empty(max(1, ws_b // 8), dtype=_F64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nat.check(nat.lib.hm_axis_statistics(val.data_ptr(), nat.ptr(std), outer, A, inner, mean.data_ptr(), sd.data_ptr(), nat.ptr(err),
                                              ws.data_ptr(), _stream(dev)), "hm_axis_statistics")
     return {"mean": mean, "std": sd, "error": err}
@@ -719,7 +744,7 @@ def pair_statistics(x, sx, y, sy, multiplier: float):
     Cc = x.shape[-1]
     out = torch.empty(6 * Cc, dtype=_F64, device=x.device)
     ws = torch.empty(nat.lib.hm_pair_statistics_workspace_bytes() // 8, dtype=_F64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         nat.check(nat.lib.hm_pair_statistics(x.data_ptr(), nat.ptr(sx), y.data_ptr(), nat.ptr(sy), float(multiplier), x.numel(), Cc,
                                              out.data_ptr(), ws.data_ptr(), _stream(x.device)), "hm_pair_statistics")
     w = sx is not None or sy is not None
@@ -763,7 +788,7 @@ def pairs_statistics(vals: Sequence[torch.Tensor], stds: Optional[Sequence[torch
     pm = (C.c_double * P)(*[float(p[2]) for p in pairs])
     out = torch.empty(P * 6 * Cc, dtype=_F64, device=dev)
     ws = torch.empty(max(1, nat.lib.hm_pairs_statistics_workspace_bytes(P) // 8), dtype=_F64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nat.check(nat.lib.hm_pairs_statistics(C.cast(vp, C.POINTER(C.c_void_p)), None if sp is None else C.cast(sp, C.POINTER(C.c_void_p)), n,
                                               pi, pj, pm, P, vals[0].numel(), Cc, lo, hi, out.data_ptr(), ws.data_ptr(), _stream(dev)),
                   "hm_pairs_statistics")
@@ -787,7 +812,7 @@ def channel_histogram(val: torch.Tensor, std: Optional[torch.Tensor], bins: int,
     Cc = val.shape[-1]
     ws = torch.empty(max(1, nat.lib.hm_histogram_workspace_bytes(int(bins), Cc) // 8), dtype=_F64, device=val.device)
     out = {}
-    with torch.cuda.device(val.device):
+    with _on(val.device):
         if included_range is None:
             mm = torch.empty(2 * Cc, dtype=_F64, device=val.device)
             nat.check(nat.lib.hm_channel_minmax(val.data_ptr(), nat.ptr(std), val.numel(), Cc, mm.data_ptr(), ws.data_ptr(),
@@ -835,7 +860,7 @@ def welford_update(frames: Sequence[torch.Tensor], count_before: int, mean: torc
         _require_cuda(f, "frame")
         if f.dtype != torch.uint8 or f.shape != mean.shape:
             raise ValueError("every frame must be a uint8 tensor shaped like mean")
-    with torch.cuda.device(dev):
+    with _on(dev):
         for k0 in range(0, len(frames), nat.HM_MAX_FRAMES):
             batch = [f.contiguous() for f in frames[k0:k0 + nat.HM_MAX_FRAMES]]
             nat.check(nat.lib.hm_welford_update(_ptr_array(batch), len(batch), count, nat.ptr(lut), mean.data_ptr(), nat.ptr(m2),
@@ -849,7 +874,7 @@ def welford_finalize(mean: torch.Tensor, m2: Optional[torch.Tensor], count: int)
     _require_cuda(mean, "mean")
     out_mean = torch.empty(mean.shape, dtype=torch.uint8, device=mean.device)
     out_std = None if m2 is None else torch.empty(mean.shape, dtype=torch.uint8, device=mean.device)
-    with torch.cuda.device(mean.device):
+    with _on(mean.device):
         nat.check(nat.lib.hm_welford_finalize(mean.data_ptr(), nat.ptr(m2), int(count), out_mean.data_ptr(), nat.ptr(out_std),
                                               mean.numel(), _stream(mean.device)), "hm_welford_finalize")
     return out_mean, out_std
@@ -891,7 +916,7 @@ def linearity_energy(dn_stack: torch.Tensor, std_stack: Optional[torch.Tensor], 
     energy = torch.empty(B, dtype=_F64, device=dev)
     out_pairs = torch.empty((B, pairs), dtype=_F64, device=dev) if return_pairs else None
     ws = torch.empty(max(1, nat.lib.hm_linearity_energy_workspace_bytes(P, N, B) // 8), dtype=_F64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         nat.check(nat.lib.hm_linearity_energy(dn_stack.data_ptr(), nat.ptr(std_stack), (C.c_double * N)(*t.tolist()), lut.data_ptr(),
                                               nat.ptr(vd), B, int(lower), int(upper), int(bool(use_relative)), P, N,
                                               nat.ptr(out_pairs), energy.data_ptr(), ws.data_ptr(), _stream(dev)),

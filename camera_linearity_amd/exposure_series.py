@@ -23,7 +23,6 @@ import torch
 
 from . import settings as gs
 from .image_set import ImageSet
-from .measurand import HipMeasurand
 
 
 def icrf_derivative(ICRF, bits: int = None):
@@ -71,9 +70,10 @@ class ExposurePair(object):
     def compute_difference_stats(self):
         """compute_difference() + compute_stats(axis=(0, 1), release_memory_after=True) in one fused HIP reduction
         (hm_pair_statistics): the two difference images are never written to HBM."""
-        from . import engine
         xs, ys = self.short_exposure.measurand, self.long_exposure.measurand
-        self.absolute_stats, self.relative_stats = engine.pair_statistics(xs._f64(), xs.std, ys._f64(), ys.std, self.exposure_ratio)
+        ab, rel = xs._eng().pair_statistics(xs._f64(), xs._std, ys._f64(), ys._std, self.exposure_ratio)
+        self.absolute_stats = {k: xs._export(v) for k, v in ab.items()}
+        self.relative_stats = {k: xs._export(v) for k, v in rel.items()}
         self.absolute_difference = None
         self.relative_difference = None
 
@@ -108,13 +108,15 @@ class ExposureSeries(object):
     @classmethod
     def from_image_set(cls, reference_image_set: ImageSet, directory_path: Optional[Path] = None):
         search_path = reference_image_set.path.parent if directory_path is None else directory_path
-        found = [s for s in ImageSet.multiple_from_path(search_path) if reference_image_set.is_exposure_match(s)]
+        found = [s for s in ImageSet.multiple_from_path(search_path, use_cupy=reference_image_set.use_cupy) if reference_image_set.is_exposure_match(s)]
         found.sort(key=lambda s: s.features["exposure"])
         return cls(directory_path=search_path, input_image_sets=found)
 
     @classmethod
-    def from_dir_path(cls, directory_path: Path):
-        return cls.from_multiple_image_sets(ImageSet.multiple_from_path(directory_path))
+    def from_dir_path(cls, directory_path: Path, use_cupy: Optional[bool] = False):
+        """exposure_series.py:148-160; `use_cupy` (an addition) picks the backend of the ImageSets it creates - the reference's
+        ImageSet default, the host backend, unless asked for the device."""
+        return cls.from_multiple_image_sets(ImageSet.multiple_from_path(directory_path, use_cupy=use_cupy))
 
     @classmethod
     def from_multiple_image_sets(cls, list_of_image_sets: List[ImageSet]):
@@ -171,24 +173,29 @@ class ExposureSeries(object):
         self.exposure_pairs = pairs
 
     # ---- the merge (exposure_series.py:317-419)
+    def _eng(self):
+        """The engine of this series' backend (the first image's: HIP library, or the host build inside nat.host_mode())."""
+        return self.input_image_sets[0].measurand._eng()
+
     def _stack_inputs(self, list_of_dark_fields, dark_threshold, with_std):
-        """Collect device tensors for the fused launch: frames (all uint8 DNs or all float64 values),
-        stds, per-frame dark DN maps + DN thresholds."""
+        """Collect the tensors for the fused launch: frames (all uint8 DNs or all float64 values), stds, per-frame dark DN maps + DN
+        thresholds - in HBM on the HIP backend, host tensors on the host backend. A dark frame held by the other backend is moved over."""
         from . import engine
         sets = self.input_image_sets
         for s in sets:
             if s.measurand.shape is None:
                 s.load_value_image()
-        all_dn = all(s.measurand.dn is not None for s in sets)
-        frames = [s.measurand.dn if all_dn else s.measurand._f64() for s in sets]
+        all_dn = all(s.measurand._dn_t() is not None for s in sets)
+        frames = [s.measurand._dn_t() if all_dn else s.measurand._f64() for s in sets]
+        dev = frames[0].device
         stds = None
         if with_std:
             for s in sets:
-                if s.measurand.std is None:
+                if s.measurand._std is None:
                     s.load_std_image()
-                if s.measurand.std is None:
+                if s.measurand._std is None:
                     raise ValueError("uncertainty propagation needs a std image for every frame")
-            stds = [s.measurand.std for s in sets]
+            stds = [s.measurand._std for s in sets]
         thr = gs.DARK_THRESHOLD if dark_threshold is None else dark_threshold
         darks, mins = None, None
         if list_of_dark_fields:
@@ -201,20 +208,21 @@ class ExposureSeries(object):
                     continue
                 if dark.measurand.shape is None:
                     dark.load_value_image()
-                if dark.measurand.dn is not None:
-                    darks.append(dark.measurand.dn)
+                if dark.measurand._dn_t() is not None:
+                    darks.append(dark.measurand._dn_t().to(dev))
                     mins.append(engine.dark_min_dn(scale, thr))
                 else:                                   # float-valued dark: 0/1 map, hot iff value*scale > thr
-                    darks.append(((dark.measurand.val * scale) > thr).to(torch.uint8))
+                    darks.append(((dark.measurand._tv() * scale) > thr).to(torch.uint8).to(dev))
                     mins.append(1)
         return frames, stds, darks, mins
 
     def _precalculate_sum_of_weights(self, list_of_dark_fields: Optional[List[ImageSet]] = None,
                                      dark_threshold: Optional[float] = None):
         """exposure_series.py:317-345 -> (S, S**2) device arrays."""
-        from . import engine
         frames, _, darks, mins = self._stack_inputs(list_of_dark_fields, dark_threshold, with_std=False)
-        return engine.sum_of_weights(frames, darks=darks, dark_min=mins, median_k=gs.MEDIAN_FILTER_KERNEL_SIZE)
+        exp = self.input_image_sets[0].measurand._export
+        S, S2 = self._eng().sum_of_weights(frames, darks=darks, dark_min=mins, median_k=gs.MEDIAN_FILTER_KERNEL_SIZE)
+        return exp(S), exp(S2)
 
     def _compute_HDR_image_set(self, list_of_dark_fields, sum_of_weights, square_sum_of_weights, ICRF, ICRF_diff,
                                flat_set: Optional[ImageSet] = None, dark_threshold: Optional[float] = None,
@@ -222,39 +230,42 @@ class ExposureSeries(object):
         """exposure_series.py:347-397. The fused kernel recomputes the sum of weights in registers, so the
         two precalculated arrays are accepted for signature compatibility and not read."""
         from . import engine
+        eng = self._eng()
         sets = self.input_image_sets
         if use_std is None:
             for s in sets:                                  # the reference loads every frame's std image (:377),
-                if s.measurand.std is None and s.path is not None:     # whether or not its value image is in memory yet
+                if s.measurand._std is None and s.path is not None:     # whether or not its value image is in memory yet
                     s.load_std_image()
-            have = [s.measurand.std is not None for s in sets]
+            have = [s.measurand._std is not None for s in sets]
             if any(have) and not all(have):
                 raise ValueError("some frames have a std image and some do not: uncertainty propagation needs one for every frame "
                                  "(pass use_std=False to merge values only)")
             use_std = all(have)
         frames, stds, darks, mins = self._stack_inputs(list_of_dark_fields, dark_threshold, with_std=use_std)
+        dev = frames[0].device
         if ICRF_diff is None and use_std:
             ICRF_diff = icrf_derivative(ICRF)
         kw = {}
         if flat_set is not None:                                   # exposure_series.py:415-417
             if flat_set.measurand.shape is None:
                 flat_set.load_value_image()
-            fval = flat_set.measurand.dn if flat_set.measurand.dn is not None else flat_set.measurand._f64()
+            fm = flat_set.measurand
+            fval = (fm._dn_t() if fm._dn_t() is not None else fm._f64()).to(dev)
             size_x = gs.IM_SIZE_X or fval.shape[0]
             size_y = gs.IM_SIZE_Y or fval.shape[1]
             x0, x1, y0, y1 = engine.flat_roi_bounds(size_x, size_y, gs.FF_MID_PERCENTAGE)
-            kw.update(flat=fval, ff_mean=engine.roi_mean(fval, x0, x1, y0, y1).cpu().numpy())
+            kw.update(flat=fval, ff_mean=eng.roi_mean(fval, x0, x1, y0, y1).cpu().numpy())
             if use_std:
-                if flat_set.measurand.std is None:
+                if fm._std is None:
                     flat_set.load_std_image()
-                if flat_set.measurand.std is None:
+                if fm._std is None:
                     raise ValueError("flat field needs a std image to propagate uncertainty")
-                kw.update(flat_std=flat_set.measurand.std,
-                          ff_std_mean=engine.roi_mean(flat_set.measurand.std, x0, x1, y0, y1).cpu().numpy())
+                fstd = fm._std.to(dev)
+                kw.update(flat_std=fstd, ff_std_mean=eng.roi_mean(fstd, x0, x1, y0, y1).cpu().numpy())
         exposures = [s.features["exposure"] for s in sets]
-        out = engine.merge(frames, exposures, ICRF, ICRF_diff if use_std else None, stds, darks=darks, dark_min=mins,
-                           median_k=gs.MEDIAN_FILTER_KERNEL_SIZE, **kw)
-        hdr = HipMeasurand(out["val"], out.get("std"))
+        out = eng.merge(frames, exposures, ICRF, ICRF_diff if use_std else None, stds, darks=darks, dark_min=mins,
+                        median_k=gs.MEDIAN_FILTER_KERNEL_SIZE, **kw)
+        hdr = type(sets[0].measurand)(out["val"], out.get("std"))
         hdr_set = ImageSet(file_path=sets[0].get_file_path_without_exposure(), features=dict(sets[0].features) if sets[0].features else None,
                            measurand=hdr)
         hdr_set.is_HDR = True
@@ -278,9 +289,9 @@ class ExposureSeries(object):
         if not self.input_image_sets:
             raise ValueError("no input images")
         if dark_list is None and gs.DEFAULT_DARK_PATH is not None:
-            dark_list = ImageSet.multiple_from_path(Path(gs.DEFAULT_DARK_PATH))
+            dark_list = ImageSet.multiple_from_path(Path(gs.DEFAULT_DARK_PATH), use_cupy=self.use_cupy)
         if flat_list is None and gs.DEFAULT_FLAT_PATH is not None:
-            flat_list = ImageSet.multiple_from_path(Path(gs.DEFAULT_FLAT_PATH))
+            flat_list = ImageSet.multiple_from_path(Path(gs.DEFAULT_FLAT_PATH), use_cupy=self.use_cupy)
         flat_set = self.input_image_sets[0].get_flat_field(flat_list) if flat_list else None
         self.merged_image_set = self._compute_HDR_image_set(dark_list, None, None, ICRF, ICRF_diff, flat_set=flat_set,
                                                             use_std=use_std)
@@ -291,7 +302,7 @@ class ExposureSeries(object):
         for image_set in self.input_image_sets:
             if image_set.measurand.shape is None:
                 image_set.load_value_image()
-            if image_set.measurand.std is None and use_std:
+            if image_set.measurand._std is None and use_std:
                 image_set.load_std_image()
         # the thresholds ride on the all-pairs launch where that applies (no separate pass over the frames); otherwise frame by frame
         if self._all_pairs_fused(lower, upper):
@@ -301,8 +312,8 @@ class ExposureSeries(object):
         if self._all_pairs_fused():
             return
         for pair in self.exposure_pairs:
-            v = pair.short_exposure.measurand.val
-            if v is not None and v.is_cuda and v.dim() == 3 and v.shape[-1] <= 4 and pair.long_exposure.measurand.shape == tuple(v.shape):
+            v = pair.short_exposure.measurand._tv()
+            if v is not None and v.dim() == 3 and v.shape[-1] <= 4 and pair.long_exposure.measurand.shape == tuple(v.shape):
                 pair.compute_difference_stats()              # fused: no difference images in HBM
             else:
                 pair.compute_difference()
@@ -312,7 +323,6 @@ class ExposureSeries(object):
         """Every pair of the series in ONE launch (hm_pairs_statistics): each frame is read from HBM once instead of once per
         pair it takes part in. Applies when the pairs are pairs of this series' own images, all images share one (H, W, C <= 4)
         shape on one device and either all or none of them carry a std; otherwise the per-pair path above runs."""
-        from . import engine
         sets = self.input_image_sets
         if not self.exposure_pairs or not sets:
             return False
@@ -322,13 +332,13 @@ class ExposureSeries(object):
         shapes = {s.measurand.shape for s in sets}
         if len(shapes) != 1 or None in shapes or len(next(iter(shapes))) != 3 or next(iter(shapes))[-1] > 4:
             return False
-        have_std = [s.measurand.std is not None for s in sets]
+        have_std = [s.measurand._std is not None for s in sets]
         if any(have_std) != all(have_std):
             return False
         vals = [s.measurand._f64() for s in sets]
-        if not all(v.is_cuda and v.device == vals[0].device for v in vals):
+        if not all(v.device == vals[0].device for v in vals) or len({s.measurand.backend for s in sets}) != 1:
             return False
-        stds = [s.measurand.std for s in sets] if all(have_std) else None
+        stds = [s.measurand._std for s in sets] if all(have_std) else None
         pairs = [(index[id(p.short_exposure)], index[id(p.long_exposure)], p.exposure_ratio) for p in self.exposure_pairs]
         thresholds = None
         if lower is not None or upper is not None:           # apply_thresholds (measurand.py:375-428) inside the launch, in place
@@ -346,8 +356,10 @@ class ExposureSeries(object):
             if stds is not None:
                 for s_, sd in zip(sets, stds):
                     s_.measurand.std = sd
-        for p, (ab, rel) in zip(self.exposure_pairs, engine.pairs_statistics(vals, stds, pairs, to_host=True, thresholds=thresholds)):
-            p.absolute_stats, p.relative_stats = ab, rel          # (host tensors: 6C numbers per pair, fetched with ONE copy)
+        exp = sets[0].measurand._export
+        for p, (ab, rel) in zip(self.exposure_pairs, self._eng().pairs_statistics(vals, stds, pairs, to_host=True, thresholds=thresholds)):
+            # (host tensors: 6C numbers per pair, fetched with ONE copy; NumPy arrays on the host backend)
+            p.absolute_stats, p.relative_stats = {k: exp(v) for k, v in ab.items()}, {k: exp(v) for k, v in rel.items()}
             p.absolute_difference = p.relative_difference = None
         return True
 

@@ -25,8 +25,8 @@ import torch
 
 from . import settings as gs
 from . import tiff_io
-from .measurand import HipMeasurand
-from .measurand_factory import Measurand
+from .measurand import HipMeasurand, HostMeasurand
+from .measurand_factory import Measurand, measurand_to_cupy, measurand_to_numpy
 
 
 def _read_image(path: Path, unchanged: bool = False) -> Optional[np.ndarray]:
@@ -45,19 +45,22 @@ def _std_path(path: Path) -> Path:
 class ImageSet(object):
 
     def __init__(self, file_path=None, value=None, std=None, features: Optional[Dict] = None,
-                 measurand: Optional[HipMeasurand] = None, use_cupy: Optional[bool] = True):
+                 measurand: Optional[HipMeasurand] = None, use_cupy: Optional[bool] = False):
+        """image_set.py:27-45, defaults included: `use_cupy=False` is the host backend (the reference's NumPy slot), `use_cupy=True`
+        the device backend (HIP in the reference's CuPy slot); a given measurand decides for itself."""
         self.path = Path(file_path) if isinstance(file_path, str) else file_path
         if measurand is not None:                       # image_set.py:37-42
-            if getattr(measurand, "backend", None) != "hip":
-                raise ValueError(f"Expected type hip, got {type(measurand)} instead.")
+            if getattr(measurand, "backend", None) not in ("hip", "numpy"):
+                raise ValueError(f"Expected a Measurand of this package, got {type(measurand)} instead.")
             self._measurand = measurand
+            self._use_cupy = measurand.backend != "numpy"
         else:
+            self._use_cupy = bool(use_cupy)
             if isinstance(value, np.ndarray) and value.dtype == np.uint8 or \
                     isinstance(value, torch.Tensor) and value.dtype == torch.uint8:
-                self._measurand = HipMeasurand.from_dn(value, std)
+                self._measurand = self._measurand_class().from_dn(value, std)
             else:
-                self._measurand = Measurand(value, std, use_cupy)
-        self._use_cupy = True
+                self._measurand = Measurand(value, std, self._use_cupy)
         if features is not None:
             self.features = features
         elif file_path is not None:
@@ -73,9 +76,13 @@ class ImageSet(object):
 
     @measurand.setter
     def measurand(self, new_measurand):
-        if getattr(new_measurand, "backend", None) != "hip":
-            raise ValueError(f"Expected type hip, got {type(new_measurand)} instead.")
+        expected_backend = "hip" if self._use_cupy else "numpy"          # image_set.py:59-77 ("cupy" there)
+        if getattr(new_measurand, "backend", None) != expected_backend:
+            raise ValueError(f"Expected type {expected_backend}, got {type(new_measurand)} instead.")
         self._measurand = new_measurand
+
+    def _measurand_class(self):
+        return HipMeasurand if self._use_cupy else HostMeasurand
 
     @property
     def use_cupy(self):
@@ -86,16 +93,21 @@ class ImageSet(object):
         raise AttributeError("use_cupy is a read-only attribute, managing the state of the used array backend.")
 
     def to_cupy(self):
-        """image_set.py:95-100 moves the image to the CuPy backend; this package's device backend is HIP and an ImageSet
-        built here already lives there."""
-        raise NotImplementedError("camera_linearity_amd keeps images on the HIP backend (measurand.backend == 'hip'); there is no CuPy backend")
+        """image_set.py:95-100: convert this ImageSet to the device backend (HIP in the CuPy slot)."""
+        self._measurand = measurand_to_cupy(self.measurand)
+        self._use_cupy = True
 
     def show_image(self):
-        """image_set.py:423-433 opens an OpenCV window; no GUI in this package - use to_numpy() with the viewer of your choice."""
-        raise NotImplementedError("show_image needs an OpenCV GUI; use ImageSet.to_numpy() and display the array yourself")
+        """image_set.py:423-433 opens an OpenCV window; no GUI in this package - use host_arrays() with the viewer of your choice."""
+        raise NotImplementedError("show_image needs an OpenCV GUI; use ImageSet.host_arrays() and display the array yourself")
 
     def to_numpy(self):
-        """(val, std) host arrays of the managed image."""
+        """image_set.py:88-93: convert this ImageSet to the host (NumPy) backend, in place."""
+        self._measurand = measurand_to_numpy(self.measurand)
+        self._use_cupy = False
+
+    def host_arrays(self):
+        """(val, std) of the managed image as NumPy arrays on the host, whatever the backend (a copy from the device on the HIP backend)."""
         return self.measurand.to_numpy()
 
     # ---- pass-throughs
@@ -176,11 +188,12 @@ class ImageSet(object):
         img = _read_image(self.path, unchanged=bool(bit64))
         if img is None:
             raise FileNotFoundError(str(self.path))
-        std = self.measurand.std
+        std = self.measurand._std
+        cls = self._measurand_class()
         if img.dtype == np.uint8 and not bit64:
-            self._measurand = HipMeasurand.from_dn(img, std)
+            self._measurand = cls.from_dn(img, std)
         else:
-            self._measurand = HipMeasurand(img.astype(np.float64), std)
+            self._measurand = cls(img.astype(np.float64), std)
 
     def load_std_image(self, STD_data=None, bit64: Optional[bool] = False):
         """image_set.py:228-243: '<name> STD.tif' as float64, else the per-DN table fallback."""
@@ -218,7 +231,7 @@ class ImageSet(object):
         """image_set.py:402-421."""
         if flatSet.measurand.shape is None:
             flatSet.load_value_image()
-        if flatSet.measurand.std is None and self.measurand.std is not None:
+        if flatSet.measurand._std is None and self.measurand._std is not None:
             flatSet.load_std_image()
         new_measurand = self.measurand.normalize_by_map(flatSet.measurand)
         return ImageSet(file_path=self.path, features=self.features, measurand=new_measurand)
@@ -231,7 +244,7 @@ class ImageSet(object):
         file_path.parent.mkdir(parents=True, exist_ok=True)
         base = str(file_path).removesuffix(".tif")
         acq_suffix, std_suffix = (" HDR.tif", " HDR STD.tif") if is_HDR else (".tif", " STD.tif")
-        val, std = self.to_numpy()
+        val, std = self.host_arrays()
         if not separate_channels:
             tiff_io.imwrite(base + acq_suffix, val.astype(np.float64))
             if std is not None:
@@ -248,7 +261,7 @@ class ImageSet(object):
         written as float64 unless force_8_bit."""
         file_path = self.path.parent.joinpath("8bit", self.path.name) if save_path is None else Path(save_path)
         file_path.parent.mkdir(parents=True, exist_ok=True)
-        val, std = self.to_numpy()
+        val, std = self.host_arrays()
         val = val.astype(np.float64, copy=True)
         max_float = np.amax(val)
         if max_float > 1:
@@ -266,7 +279,7 @@ class ImageSet(object):
     def save_npy(self, save_path: Path, is_HDR: bool = False):
         """Host-side dump of val (and std) as .npy next to each other ('<name> HDR.npy', '<name> HDR STD.npy' -
         the naming of save_64bit, image_set.py:285-290)."""
-        val, std = self.to_numpy()
+        val, std = self.host_arrays()
         base = str(save_path).removesuffix(Path(save_path).suffix)
         np.save(base + (" HDR" if is_HDR else "") + ".npy", val)
         if std is not None:
@@ -293,14 +306,14 @@ class ImageSet(object):
         return ImageSet(features=short_exposure_set.features, measurand=m)
 
     @classmethod
-    def multiple_from_path(cls, path: Path):
+    def multiple_from_path(cls, path: Path, use_cupy: Optional[bool] = False):
         """image_set.py:482-501 (also picks up .npy files)."""
         out = []
         root = path if hasattr(path, "glob") else Path(path)
         for pattern in ("*.tif", "*.npy"):
             for file in sorted(root.glob(pattern)):
                 if "STD" not in file.name:
-                    out.append(cls(file_path=file))
+                    out.append(cls(file_path=file, use_cupy=use_cupy))
         return out
 
 

@@ -181,27 +181,27 @@ def test_exposure_series_process_hdr_image(golden):
     gs.configure(DARK_THRESHOLD=float(g["dark_threshold"]), FF_MID_PERCENTAGE=float(g["ff_mid"]),
                  MEDIAN_FILTER_KERNEL_SIZE=int(g["median_k"]))
     try:
-        sets = [ImageSet(value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
-        darks = [ImageSet(value=g[k], features=dict(_features(e), subject="dark"))
+        sets = [ImageSet(use_cupy=True, value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+        darks = [ImageSet(use_cupy=True, value=g[k], features=dict(_features(e), subject="dark"))
                  for k, e in (("dark16", 0.016), ("dark32", 0.032), ("dark64", 0.064))]
-        flat = ImageSet(value=g["flat"], std=g["flat_std"], features=dict(_features(0.01), subject="flat"))
+        flat = ImageSet(use_cupy=True, value=g["flat"], std=g["flat_std"], features=dict(_features(0.01), subject="flat"))
         series = ExposureSeries(input_image_sets=sets)
         series.process_HDR_image(g["icrf"], g["icrf_diff"], dark_list=darks, flat_list=[flat])
-        val, std = series.merged_image_set.to_numpy()
+        val, std = series.merged_image_set.host_arrays()
         np.testing.assert_allclose(val, g["val_ff"], rtol=1e-12)
         np.testing.assert_allclose(std, g["std_ff"], rtol=1e-9)
         assert series.merged_image_set.is_HDR and series.merged_image_set.measurand.backend == "hip"
         # ICRF_diff derived with the reference's gradient convention when not given
         series.process_HDR_image(g["icrf"], dark_list=darks)
-        val, std = series.merged_image_set.to_numpy()
+        val, std = series.merged_image_set.host_arrays()
         np.testing.assert_allclose(val, g["val"], rtol=1e-12)
         np.testing.assert_allclose(std, g["std"], rtol=1e-9)
         # val-only (no std images)
-        sets2 = [ImageSet(value=g["frames"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+        sets2 = [ImageSet(use_cupy=True, value=g["frames"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
         s2 = ExposureSeries(input_image_sets=sets2)
         s2.process_HDR_image(g["icrf"])
         assert s2.merged_image_set.measurand.std is None
-        np.testing.assert_allclose(s2.merged_image_set.to_numpy()[0], g["val_nohot"], rtol=1e-12)
+        np.testing.assert_allclose(s2.merged_image_set.host_arrays()[0], g["val_nohot"], rtol=1e-12)
         # S and S**2 (exposure_series.py:317-345)
         S, S2 = ExposureSeries(input_image_sets=sets2)._precalculate_sum_of_weights()
         ref = orc.merge(list(g["frames"]), g["exposures"], g["icrf"])
@@ -209,13 +209,13 @@ def test_exposure_series_process_hdr_image(golden):
         # stack-wide linearize and per-image pass-throughs
         lin = series.linearize(g["icrf"], g["icrf_diff"])
         v0, s0, _ = orc.linearize(orc.unit_from_u8(g["frames"][0]), g["stds"][0], g["icrf"], g["icrf_diff"])
-        np.testing.assert_array_equal(lin.input_image_sets[0].to_numpy()[0], v0)
+        np.testing.assert_array_equal(lin.input_image_sets[0].host_arrays()[0], v0)
         filt = sets[6].bad_pixel_filter(darks[2])
         refv = orc.hot_pixel_filter(orc.unit_from_u8(g["frames"][6]), orc.unit_from_u8(g["dark64"]), float(g["dark_threshold"]), 3)
-        np.testing.assert_array_equal(filt.to_numpy()[0], refv)
+        np.testing.assert_array_equal(filt.host_arrays()[0], refv)
         scaled = darks[2].scale_to_exposure(0.032)
         assert scaled.features["exposure"] == 0.032 and darks[2].features["exposure"] == 0.064      # deviation I
-        np.testing.assert_allclose(scaled.to_numpy()[0], 0.5 * orc.unit_from_u8(g["dark64"]), rtol=1e-15)
+        np.testing.assert_allclose(scaled.host_arrays()[0], 0.5 * orc.unit_from_u8(g["dark64"]), rtol=1e-15)
     finally:
         gs.configure(DARK_THRESHOLD=old[0], FF_MID_PERCENTAGE=old[1], MEDIAN_FILTER_KERNEL_SIZE=old[2])
 
@@ -228,11 +228,11 @@ def test_exposure_series_scaled_dark_selection(golden):
     old = gs.DARK_THRESHOLD
     gs.configure(DARK_THRESHOLD=float(g["dark_threshold"]))
     try:
-        sets = [ImageSet(value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
-        darks = [ImageSet(value=g["darks"][i], features=dict(_features(e), subject="dark")) for i, e in enumerate(g["dark_exposures"])]
+        sets = [ImageSet(use_cupy=True, value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+        darks = [ImageSet(use_cupy=True, value=g["darks"][i], features=dict(_features(e), subject="dark")) for i, e in enumerate(g["dark_exposures"])]
         series = ExposureSeries(input_image_sets=sets)
         series.process_HDR_image(g["icrf"], g["icrf_diff"], dark_list=darks)
-        val, std = series.merged_image_set.to_numpy()
+        val, std = series.merged_image_set.host_arrays()
         np.testing.assert_allclose(val, g["val"], rtol=1e-12)
         np.testing.assert_allclose(std, g["std"], rtol=1e-9)
     finally:
@@ -243,7 +243,7 @@ def test_exposure_pairs_and_linearity_stats():
     from camera_linearity_amd.exposure_series import ExposureSeries
     from camera_linearity_amd.image_set import ImageSet
     frames, stds, t = orc.synthetic_stack(5, 4, 16, 12, with_std=True)
-    sets = [ImageSet(value=orc.unit_from_u8(f), std=s, features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
+    sets = [ImageSet(use_cupy=True, value=orc.unit_from_u8(f), std=s, features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
     series = ExposureSeries(input_image_sets=sets)
     series.initialize_exposure_pairs()
     assert len(series.exposure_pairs) == 6
@@ -419,7 +419,7 @@ def test_all_pairs_fused_linearity(use_std):
     n, h, w = 7, 37, 29
     frames, stds, _ = orc.synthetic_stack(8, n, h, w, with_std=True)
     t = 1e-3 * 1.6 ** np.arange(n)                                       # ratios >= 0.1 for |i - j| <= 4: 18 pairs
-    sets = [ImageSet(value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
+    sets = [ImageSet(use_cupy=True, value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
     series = ExposureSeries(input_image_sets=sets)
     series.initialize_exposure_pairs()
     assert len(series.exposure_pairs) == 18
@@ -735,7 +735,7 @@ def test_process_linearity_thresholds_in_place(use_std, h, w, n):
     from camera_linearity_amd.image_set import ImageSet
     frames, stds, _ = orc.synthetic_stack(21, n, h, w, with_std=True)
     t = 1e-3 * (1.7 if n == 5 else 1.6) ** np.arange(n)                       # n = 7: 18 pairs, i.e. two launches (HM_PAIRS_MAX = 16)
-    sets = [ImageSet(value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
+    sets = [ImageSet(use_cupy=True, value=orc.unit_from_u8(f), std=(s if use_std else None), features=_features(ti)) for f, s, ti in zip(frames, stds, t)]
     series = ExposureSeries(input_image_sets=sets)
     series.initialize_exposure_pairs()
     icrf, _ = orc.synthetic_icrf((1.0, 1.0, 1.0))

@@ -232,14 +232,14 @@ def test_from_dir_path_tiff_workflow(eng, tmp_path):
         name = f"{ti * 1000:g}ms bf 5x sample.tif"
         tiff_io.imwrite(tmp_path / name, f)
         tiff_io.imwrite(tmp_path / name.replace(".tif", " STD.tif"), s)
-    sets = ImageSet.multiple_from_path(tmp_path)
+    sets = ImageSet.multiple_from_path(tmp_path, use_cupy=True)
     assert len(sets) == 4 and sorted(s.features["exposure"] for s in sets) == sorted(t.tolist())
     assert all(s.features["illumination"] == "bf" and s.features["magnification"] == "5x" for s in sets)
-    series_list = ExposureSeries.from_dir_path(tmp_path)
+    series_list = ExposureSeries.from_dir_path(tmp_path, use_cupy=True)
     series = series_list[0] if isinstance(series_list, list) else series_list
     assert len(series.input_image_sets) == 4
     series.process_HDR_image(icrf, diff)
-    val, std = series.merged_image_set.to_numpy()
+    val, std = series.merged_image_set.host_arrays()
     ref = orc.merge(frames, t, icrf, diff, stds=stds)
     np.testing.assert_allclose(val, ref["val"], rtol=1e-12)
     np.testing.assert_allclose(std, ref["std"], rtol=1e-9)
@@ -278,21 +278,21 @@ def test_std_images_load_after_value_images(eng, tmp_path):
     frames, stds, t = orc.synthetic_stack(12, 3, 24, 40, with_std=True)
     icrf, diff = orc.synthetic_icrf()
     _write_series(tiff_io, tmp_path / "a", frames, stds, t)
-    series = ExposureSeries.from_dir_path(tmp_path / "a")[0]
+    series = ExposureSeries.from_dir_path(tmp_path / "a", use_cupy=True)[0]
     series.load_value_images()
     assert all(s.measurand.std is None for s in series.input_image_sets)
     series.process_HDR_image(icrf, diff)
-    val, std = series.merged_image_set.to_numpy()
+    val, std = series.merged_image_set.host_arrays()
     ref = orc.merge(frames, t, icrf, diff, stds=stds)
     assert std is not None
     np.testing.assert_allclose(val, ref["val"], rtol=1e-12)
     np.testing.assert_allclose(std, ref["std"], rtol=1e-9)
     _write_series(tiff_io, tmp_path / "b", frames, [stds[0], None, stds[2]], t)
-    partial = ExposureSeries.from_dir_path(tmp_path / "b")[0]
+    partial = ExposureSeries.from_dir_path(tmp_path / "b", use_cupy=True)[0]
     with pytest.raises(ValueError):
         partial.process_HDR_image(icrf, diff)
     partial.process_HDR_image(icrf, diff, use_std=False)
-    np.testing.assert_allclose(partial.merged_image_set.to_numpy()[0], ref["val"], rtol=1e-12)
+    np.testing.assert_allclose(partial.merged_image_set.host_arrays()[0], ref["val"], rtol=1e-12)
 
 
 def test_process_hdr_image_default_arguments(eng, tmp_path):
@@ -317,20 +317,20 @@ def test_process_hdr_image_default_arguments(eng, tmp_path):
     _write_series(tiff_io, tmp_path / "darks", [dark, dark, dark], [None] * 3, [0.05, 0.1, 0.4], tag="bf 5x dark")
     _write_series(tiff_io, tmp_path / "flats", [flat], [flat_std], [0.1], tag="bf 5x flat")
     np.savetxt(tmp_path / "icrf.txt", icrf)
-    series = ExposureSeries.from_dir_path(tmp_path / "series")[0]
+    series = ExposureSeries.from_dir_path(tmp_path / "series", use_cupy=True)[0]
     with pytest.raises(ValueError):
         series.process_HDR_image()
     saved = {k: getattr(settings, k) for k in ("ICRF_CALIBRATED_FILE", "DEFAULT_DARK_PATH", "DEFAULT_FLAT_PATH")}
     try:
         settings.configure(ICRF_CALIBRATED_FILE=tmp_path / "icrf.txt", DEFAULT_DARK_PATH=tmp_path / "darks", DEFAULT_FLAT_PATH=tmp_path / "flats")
         series.process_HDR_image()
-        val, std = series.merged_image_set.to_numpy()
+        val, std = series.merged_image_set.host_arrays()
     finally:
         settings.configure(**saved)
-    explicit = ExposureSeries.from_dir_path(tmp_path / "series")[0]
-    explicit.process_HDR_image(np.loadtxt(tmp_path / "icrf.txt"), None, dark_list=ImageSet.multiple_from_path(tmp_path / "darks"),
-                               flat_list=ImageSet.multiple_from_path(tmp_path / "flats"))
-    ev, es = explicit.merged_image_set.to_numpy()
+    explicit = ExposureSeries.from_dir_path(tmp_path / "series", use_cupy=True)[0]
+    explicit.process_HDR_image(np.loadtxt(tmp_path / "icrf.txt"), None, dark_list=ImageSet.multiple_from_path(tmp_path / "darks", use_cupy=True),
+                               flat_list=ImageSet.multiple_from_path(tmp_path / "flats", use_cupy=True))
+    ev, es = explicit.merged_image_set.host_arrays()
     assert np.array_equal(val, ev) and np.array_equal(std, es)
     fval = orc.unit_from_u8(flat)
     dv = orc.unit_from_u8(dark)

@@ -153,8 +153,10 @@ def test_measurand_constructor_errors_and_properties():
     m.val = np.zeros((4, 5, 3))
     assert list(m.channels.cpu().numpy()) == [0, 1, 2]                   # deviation B: arange(shape[-1])
     assert HipMeasurand(torch.zeros((2, 2, 4), dtype=torch.float64)).channels.numel() == 4
-    with pytest.raises(NotImplementedError):
-        Measurand(np.zeros(3), use_cupy=False)
+    hm = Measurand(np.zeros(3), use_cupy=False)                          # the host backend in the reference's NumPy slot
+    assert hm.backend == "numpy" and isinstance(hm.val, np.ndarray) and type(hm).__name__ == "HostMeasurand"
+    with pytest.raises(TypeError, match="Invalid other type"):
+        m._normalize_input(hm)                                           # backends do not mix (sibling classes in the reference)
     assert Measurand().val is None and Measurand().backend == "hip"
     assert is_broadcastable((4, 1, 3), (5, 3)) and not is_broadcastable((4, 2), (3,))
     with pytest.raises(ValueError):
@@ -168,10 +170,11 @@ def test_image_set_backend_checks_and_dark_selection():
     from camera_linearity_amd.measurand import HipMeasurand
 
     class Fake:
-        backend = "numpy"
+        backend = "cupy"
     with pytest.raises(ValueError):
         ImageSet(measurand=Fake())
-    s = ImageSet(value=np.zeros((2, 2, 3), np.uint8), features={"exposure": 0.04, "illumination": "bf", "magnification": "5x", "subject": "a"})
+    assert ImageSet().use_cupy is False and ImageSet().measurand.backend == "numpy"      # image_set.py:29: the reference's default
+    s = ImageSet(use_cupy=True, value=np.zeros((2, 2, 3), np.uint8), features={"exposure": 0.04, "illumination": "bf", "magnification": "5x", "subject": "a"})
     with pytest.raises(AttributeError):
         s.use_cupy = False
     with pytest.raises(ValueError):
