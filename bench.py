@@ -730,7 +730,7 @@ def main():
     torch.cuda.synchronize()
     kernel_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in per]
     # the box's copy rate (the library's nontemporal 16-byte copy kernel between two output buffers, after the timed region): the merge's
-    # traffic is ~half reads, ~half writes, and a plain copy is what the memory system sustains for such a mix (DESIGN.md 4.4)
+    # traffic is ~half reads, ~half writes, and a plain copy is what the memory system sustains for such a mix (DESIGN.md 4.1)
     copy_gbps = None
     pair_ = None
     if len(plans) > 1 and "val" in plans[0].outputs and "val" in plans[1].outputs:

@@ -45,7 +45,7 @@ extern "C" int hm_gaussian_weight_lut_host(double* w_lut, double* dw_lut) {
 }
 
 
-// Shader-clock probe (diagnostic): ONE wave on a side stream samples s_memtime (shader cycles) and s_memrealtime (100 MHz)
+// Shader-clock probe (diagnostic; docs/DESIGN_history_r01_r02.md 4.4): ONE wave on a side stream samples s_memtime (shader cycles) and s_memrealtime (100 MHz)
 // at its start and after `spins` sleep periods, while the caller's kernels run on another stream: out[0] = shader cycles, out[1] = 100 MHz
 // ticks, so clock [GHz] = out[0] / out[1] / 10. The values go to a buffer of their own; nothing else reads them.
 namespace hm {

@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void merge_patch_hot(const MergeK a, const uin
 //   TAB_PLAIN   w[256] | wg[256*3]  (8-byte entries, two ds_read_b64 per (element, frame))        8 KB
 //   TAB_FUSED   {w, wg}[256*3] as 16-byte entries, one ds_read_b128 per (element, frame)          12 KB
 //   TAB_NONE    (tuning probe only, wrong results) no gather at all: the HBM ceiling of the access pattern
-// Replicating the tables across banks was measured and dropped: only a full private copy
+// Replicating the tables across banks was measured and dropped (docs/DESIGN_history_r01_r02.md 4.4): only a full private copy
 // per lane of an LDS lane group removes the ~2.4-way conflicts random DNs cause, and that needs 64 KB per
 // 256-entry float64 table, i.e. one workgroup per CU, which loses more latency hiding than it gains.
 // The std kernel uses {w,dw}[256] and {g,d}[768] as 16-byte entries (16 KB).
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
         double* og = a.out_val + static_cast<int64_t>(unit) * UNIT + wave_el;                // scalar base of the wave's output in this unit
         double held[DEFER ? U : 1][2];
         if constexpr (PIPE) {
-            // software-pipelined gathers (VERDICT r2 item 7 / DESIGN 9.1): two sets of gathered {w, w g} pairs; the ds_read_b128 of the next
+            // software-pipelined gathers ("software-pipelined LDS gathers"): two sets of gathered {w, w g} pairs; the ds_read_b128 of the next
             // bundle of HM_FB frames (of this or the next sub-unit) are in flight while the current bundle's add / fma chain runs
             constexpr int NB = (NF + HM_FB - 1) / HM_FB;
             double2 T[2][HM_FB][2];
@@ -1750,7 +1750,7 @@ __global__ __launch_bounds__(256) HM_LOOP_STD_ATTR void merge_u8_loop_std(const 
 // re-evaluates the weights in its second pass. Stacks of up to 8 frames keep the frame VALUES in registers between
 // the passes; larger ones re-read them (not the weights: with exp() stubbed out the kernel is 1.5 % faster, it is
 // bound by memory traffic, and the re-read misses the caches). merge_generic evaluated exp() twice per
-// element-frame even for val-only and moved 8-byte pieces: 1 307 -> see DESIGN.md 8 for the numbers.
+// element-frame even for val-only and moved 8-byte pieces: 1 307 -> see docs/DESIGN_history_r01_r02.md section 8 for the numbers.
 // ------------------------------------------------------------------------------------------------
 constexpr int kF64Chunk = 4;
 constexpr int kF64Keep = 8;        // std mode: stacks up to this size keep their frame values in registers between the passes

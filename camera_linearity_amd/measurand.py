@@ -395,7 +395,7 @@ class HipMeasurand(AbstractMeasurand):
 
     def compute_kernel_density_estimate(self, data_points: int, included_range=None, channels=None, use_std: bool = False):
         """modules/measurand.py:716-761 is a NumPy-only plotting helper of the reference (scipy.stats.gaussian_kde on host arrays)
-        and is out of scope here (DESIGN.md 10): this package computes on the device only."""
+        and is out of scope here (DESIGN.md section 9): this package computes on the device only."""
         raise NotImplementedError("kernel density estimates are host-side plotting support in the reference; "
                                   "use to_numpy() and scipy.stats.gaussian_kde")
 

@@ -1,7 +1,7 @@
 """Streaming many host-resident exposure stacks through one GPU (BASELINE config 5: a batch of independent stacks).
 
 A single merge is 0.14 ms of kernel time between 6 ms of host-to-device and 7 ms of device-to-host copy (config 2,
-DESIGN.md 8), so for a stream of stacks the copies are the pipeline. `MergePipeline` overlaps them: the H2D copy of
+DESIGN.md section 6), so for a stream of stacks the copies are the pipeline. `MergePipeline` overlaps them: the H2D copy of
 stack k+1, the fused merge of stack k and the D2H copy of stack k-1 run on three HIP streams, ordered by events,
 over `depth` slots of pinned host staging and device buffers. PCIe is full duplex, so the steady state costs
 max(H2D, D2H) per stack instead of their sum.
