@@ -491,9 +491,13 @@ def linearity_workload(a, dev, rank=0, world=1, dist=None):
     E = H * W * 3
     alg = n * 8 * (2 if use_std else 1) * E             # every frame (and std) byte once
     steps, warmup = min(a.steps, 100), min(a.warmup, 10)
-    t_end = time.perf_counter() + a.prewarm_s
+    # untimed clock pre-warm: this kernel is FP64-VALU bound, so its time IS the shader clock - and after the seconds of host-side set-up
+    # above the clock needs ~2 s of load to settle (0.5 s of pre-warm measured 2 790-3 575 us per launch, 3 s 2 457-2 460 us on the same
+    # box in the same call: tools/lin_var.sh, profiles/r04_lin_prewarm.log). The HBM-bound merges settle within the default 0.5 s.
+    t_end = time.perf_counter() + max(a.prewarm_s, 3.0)
     while time.perf_counter() < t_end:
-        launch()
+        for _ in range(20):
+            launch()
         torch.cuda.synchronize()
     for _ in range(warmup):
         launch()
