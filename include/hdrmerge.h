@@ -22,7 +22,7 @@
  *     (modules/image_set.py:223); BITS = 256, MAX_DN = 255 (modules/global_settings.py:35-37);
  *   - return value: HM_OK (0) or a negative HM_E* code; nothing throws. hm_strerror() names it.
  *
- * Two libraries export this ABI. libhdrmerge.so (csrc/*.hip) is the MI355X build described above. libhdrmerge_host.so
+ * Two libraries export this ABI. libhdrmerge.so (the .hip files under csrc/) is the MI355X build described above. libhdrmerge_host.so
  * (csrc_host/hm_host.cpp, plain C++) is the HOST build behind Measurand(use_cupy=False) - the slot of the reference's NumpyMeasurand
  * (modules/measurand_factory.py:10-14): every pointer is then a HOST pointer, `stream` is ignored, calls are synchronous and workspaces
  * may be NULL; hm_welford_* and hm_linearity_energy are device-only there (HM_EUNSUPPORTED), the hm_tiff_* decoders are not exported.
