@@ -285,8 +285,12 @@ class RowTileSet:
         `self.assembly_path` names the path the last call took. The returned tensors ARE this object's image buffers: the next
         assemble() (the next stack of a loop) overwrites them. copy=True returns tensors of the caller's own instead."""
         collective = self.world > 1 or group is not None
-        if collective and shared:
+        if collective:
             import torch.distributed as dist
+            if group is None and dist.get_backend() == "nccl":
+                raise ValueError("RowTileSet.assemble exchanges host tensors: pass a CPU process group (dist.new_group(backend='gloo')) "
+                                 "when the default group is nccl")
+        if collective and shared:
             W, Cc, with_std = self._agree_shape(group)
             key = (self.height, W, Cc, with_std)
             if getattr(self, "_shared_key", None) != key:
