@@ -20,8 +20,13 @@
 // which is the correctly rounded delta / n whenever r = RN(1 / n) and nothing underflows (Markstein's final
 // division step; Brisebarre, Muller, Raina, IEEE TC 53(8) 2004, "division when the divisor is known in
 // advance"). 3 dependent ops instead of the ~14-instruction IEEE sequence (FP64 VALU: 4 cycles per wave op).
-// The range condition is checked, not assumed: a lane whose delta is non-zero and below 2^-900, or whose
-// inputs are not finite (state, table), redoes its elements with the full division (welford_exact).
+// The range condition is checked, not assumed - once per element and launch, not per frame (round 4: the per-frame test was 2 of the 13.8
+// VALU instructions of an element-frame in a kernel that is FP64-VALU bound): the fast path needs every non-zero delta >= 2^-900.
+// With table entries that are 0 or in [2^-500, 2^500] (checked while the table is built), an incoming mean that is 0 or in
+// [2^-540, 2^500] (checked at load) and n <= 2^40 (checked on the host), every later mean is 0 or >= 2^-632 in magnitude:
+// m' = m (1 - 1/n) + f/n can lose 52 bits to ONE cancellation (two doubles >= 2^-541 differ by >= 2^-593 when they differ), after which
+// a non-zero f/n >= 2^-540 dwarfs it and a run of f = 0 shrinks it by n0/n >= 2^-40 at most - so a non-zero delta = f - m is >= 2^-684.
+// A lane whose state or table is outside those ranges (or not finite) redoes its elements with the full division (welford_exact).
 #include "hm_common.h"
 
 namespace hm {
@@ -59,7 +64,7 @@ __device__ __forceinline__ void welford_exact(const WelfordK& a, const double* t
     }
 }
 
-// G frames starting at k0 for the lane's two elements; returns false if a step left the fast division's range
+// G frames starting at k0 for the lane's two elements (fast division: the caller has checked its range, see the file header)
 template <bool M2, int G, bool VEC>
 __device__ __forceinline__ bool welford_group(const WelfordK& a, const double* t, int k0, int64_t e, uint32_t c0, uint32_t c1,
                                               double& cnt, double (&m)[2], double (&q)[2]) {
@@ -86,7 +91,6 @@ __device__ __forceinline__ bool welford_group(const WelfordK& a, const double* t
             const double delta = f[k][j] - m[j];                                  // :205
             const double q0 = delta * r;
             const double quot = fma(fma(-q0, cnt, delta), r, q0);                 // == delta / cnt
-            ok = ok && (fabs(delta) >= 0x1p-900 || delta == 0.0);
             m[j] = m[j] + quot;                                                   // :206
             if (M2) q[j] = q[j] + delta * (f[k][j] - m[j]);                       // :208
         }
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void k_welford(const WelfordK a) {
             m[0] = a.mean[e]; m[1] = a.mean[e + 1];
             if (M2) { q[0] = a.m2[e]; q[1] = a.m2[e + 1]; }
         }
-        bool ok = table_ok && fabs(m[0]) <= 0x1p500 && fabs(m[1]) <= 0x1p500 && fabs(q[0]) <= 0x1p900 && fabs(q[1]) <= 0x1p900;
+        auto mean_ok = [](double x) { const double ax = fabs(x); return x == 0.0 || (ax >= 0x1p-540 && ax <= 0x1p500); };
+        bool ok = table_ok && mean_ok(m[0]) && mean_ok(m[1]) && fabs(q[0]) <= 0x1p900 && fabs(q[1]) <= 0x1p900;
         double cnt = a.count0;
         int k0 = 0;
         if (vec_ok) {

@@ -62,6 +62,45 @@ def test_welford_state_bit_exact(eng, shape, n, with_icrf, batch):
     assert np.array_equal(mean2.cpu().numpy(), mean_ref)
 
 
+@pytest.mark.parametrize("case", ["signed_table", "tiny_entry", "tiny_state", "huge_state", "nan_state", "zero_runs"])
+def test_welford_fast_division_range(eng, case):
+    """The fast delta / n (reciprocal from the host + two FMAs) is taken only where its range argument holds - table entries 0 or in
+    [2^-500, 2^500], incoming mean 0 or in [2^-540, 2^500] - and the full division otherwise: both give the oracle's bits. Signed tables
+    make the running mean cancel (the worst case of the argument), runs of zero-valued frames shrink it."""
+    rng = np.random.default_rng(len(case))
+    shape, n = (9, 14, 3), 41
+    clip = rng.integers(0, 256, (n,) + shape, dtype=np.uint8)
+    icrf = np.linspace(0, 1, 256)[:, None] ** np.array([1.7, 2.0, 2.3])[None, :]
+    mean0 = np.zeros(shape)
+    if case == "signed_table":
+        icrf = icrf - 0.37                                                 # both signs: m (1 - 1/n) + f/n cancels
+        icrf[100] = -icrf[101]
+    elif case == "tiny_entry":
+        icrf[7, 1] = 1e-200                                                # outside [2^-500, 2^500]: the whole launch takes the exact path
+    elif case == "tiny_state":
+        mean0[2, 3, 1] = 1e-250
+        mean0[4, 5, 0] = -3e-300
+    elif case == "huge_state":
+        mean0[1, 1, 2] = 1e200
+    elif case == "nan_state":
+        mean0[0, 0, 0] = np.nan
+    elif case == "zero_runs":
+        clip[5:30] = 0                                                     # ICRF[0] = 0: twenty-five frames of f = 0
+        icrf[0] = 0.0
+    count0 = 3 if case.endswith("state") else 0
+    m2_0 = np.abs(mean0) * 0.0
+    with np.errstate(all="ignore"):
+        mean_ref, m2_ref, cnt = orc.welford_state(list(clip), icrf, True, mean=mean0.copy(), m2=m2_0.copy(), count=count0)
+    mean, m2 = dev(mean0), dev(m2_0)
+    frames = [dev(f) for f in clip]
+    count = count0
+    for k0 in range(0, n, 16):
+        count = eng.welford_update(frames[k0:k0 + 16], count, mean, m2, icrf)
+    assert count == cnt
+    np.testing.assert_array_equal(mean.cpu().numpy(), mean_ref)
+    np.testing.assert_array_equal(m2.cpu().numpy(), m2_ref)
+
+
 def test_welford_unaligned_and_odd(eng):
     """Odd element count and frames at odd byte offsets take the scalar path: same bits."""
     rng = np.random.default_rng(5)
