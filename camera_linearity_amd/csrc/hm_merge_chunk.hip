@@ -47,7 +47,6 @@ struct ChunkK {
     int64_t n_elems, elem0, in_off, H, W, row0, buf_row0;
     int32_t n_frames, C, median_k, has_flat;
     int32_t first, last;           // first / last chunk of the stack
-    int32_t want_val;              // PH_S launches of a sum-of-weights-only call never touch out_val
 };
 
 enum { PH_S = 0, PH_VAL = 1, PH_STD = 2 };
@@ -287,7 +286,7 @@ int merge_chunked(const hm_merge_args* g, int chunk_frames, std::string* describ
             k.n_elems = E; k.elem0 = 0; k.in_off = in_off;
             k.H = g->height; k.W = g->width; k.row0 = g->row0; k.buf_row0 = g->buf_row0;
             k.n_frames = n; k.C = C; k.median_k = hot ? g->median_k : 3; k.has_flat = (g->flat_u8 || g->flat_f64) ? 1 : 0;
-            k.first = k0 == 0; k.last = k0 + n == N; k.want_val = g->out_val != nullptr;
+            k.first = k0 == 0; k.last = k0 + n == N;
             const int rc = launch_chunk(k, f64in, phase, hot, vec, st);
             if (rc != HM_OK) return rc;
         }
