@@ -352,6 +352,9 @@ __device__ __forceinline__ double max0_nan_to_zero(double x) {
 }
 // LEAN: every lane of the wave already has its shift K (haveK set), so the two selects that look for the first valid element are
 // dead - the caller checks that with one ballot per iteration (pair_process_any). Same bits either way.
+#ifndef HM_PAIR_EXEC
+#define HM_PAIR_EXEC 1       // round 4: all-pairs statistics 2 456-2 469 -> 2 337-2 341 us with std, 1 208-1 213 -> 1 154-1 161 us without (one box,
+#endif                       // two runs each, profiles/r04k_pair_exec_ab.log); 0 = the select form
 template <bool WEIGHTED, bool LEAN = false>
 __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, double s) {
     bool use;
@@ -363,6 +366,26 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
         use = vw == vw;
     } else {
         use = v == v;
+    }
+    if constexpr (HM_PAIR_EXEC != 0) {
+        // EXEC-masked form: the lanes whose element NumPy's nan-functions skip sit out the accumulation (a real branch - the empty volatile asm
+        // keeps the compiler from turning it back into selects, which cost 4-6 of the 19 VALU instructions of a state and element; the branch
+        // itself is scalar-unit work). Same arithmetic on the participating lanes: the same bits.
+        if (use) {
+            asm volatile("" ::: "memory");
+            if constexpr (!LEAN) {
+                if (!a.haveK) { asm volatile("" ::: "memory"); a.K = v; }
+                a.haveK = true;
+            }
+            const double d = v - a.K;
+            if constexpr (WEIGHTED) {
+                const double t = w * d;
+                a.S0 += w; a.S1 += t; a.S2 = fma(t, d, a.S2);
+            } else {
+                a.S0 += 1.0; a.S1 += d; a.S2 = fma(d, d, a.S2);
+            }
+        }
+        return;
     }
     if constexpr (!LEAN) {
         a.K = (!a.haveK && use) ? v : a.K;
