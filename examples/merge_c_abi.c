@@ -1,4 +1,5 @@
-/* merge_c_abi.c - libhdrmerge.so from plain C: no Python, no torch, only the HIP runtime for device memory.
+/* merge_c_abi.c - libhdrmerge.so (or, with -DHM_HOST_BUILD, libhdrmerge_host.so) from plain C: no Python, no torch, only the HIP
+ * runtime for device memory - and not even that for the host build, whose entry points take host pointers.
  *
  * Merges a small synthetic exposure stack (uint8 frames, val + std) with hm_merge and checks the result against a
  * straightforward host loop over the formulas of modules/exposure_series.py:340,388-389,394 (this file's own few
@@ -7,8 +8,26 @@
  *   gcc -std=c11 -O2 -D__HIP_PLATFORM_AMD__ examples/merge_c_abi.c -Iinclude -I/opt/rocm/include \
  *       -Lcamera_linearity_amd/lib -lhdrmerge -L/opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/camera_linearity_amd/lib -Wl,-rpath,/opt/rocm/lib -lm -o /tmp/merge_c_abi && /tmp/merge_c_abi
+ *
+ * Host build of the same ABI (tests/test_host_backend.py::test_c_abi_example_host_build; runs without a GPU):
+ *
+ *   gcc -std=c11 -O2 -DHM_HOST_BUILD examples/merge_c_abi.c -Iinclude -Lcamera_linearity_amd/lib -lhdrmerge_host \
+ *       -Wl,-rpath,$PWD/camera_linearity_amd/lib -lm -o /tmp/merge_c_abi_host && /tmp/merge_c_abi_host
  */
+#ifndef HM_HOST_BUILD
 #include <hip/hip_runtime_api.h>
+#else                                   /* host build: "device" memory is host memory, the stream is NULL */
+#include <stdlib.h>
+#include <string.h>
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+static const char* hipGetErrorString(hipError_t e) { (void)e; return "out of memory"; }
+static hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 1; }
+static hipError_t hipMemcpy(void* d, const void* s, size_t n, int kind) { (void)kind; memcpy(d, s, n); return hipSuccess; }
+static hipError_t hipStreamCreate(hipStream_t* s) { *s = NULL; return hipSuccess; }
+static hipError_t hipStreamSynchronize(hipStream_t s) { (void)s; return hipSuccess; }
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>

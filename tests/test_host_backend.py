@@ -256,3 +256,22 @@ def test_host_library_exports_the_abi():
     h = nat.host_lib()
     assert all(hasattr(h, name) for name in declared), [n for n in declared if not hasattr(h, n)]
     assert h.hm_version() == nat.HM_ABI_VERSION
+
+
+def test_c_abi_example_host_build(tmp_path):
+    """examples/merge_c_abi.c compiled with -DHM_HOST_BUILD against libhdrmerge_host.so: the same C program that drives the device
+    library (tests/test_gpu_api.py::test_c_abi_example_from_plain_c), with host pointers and no HIP - and no GPU."""
+    import pathlib
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    root = pathlib.Path(__file__).resolve().parent.parent
+    lib = root / "camera_linearity_amd" / "lib"
+    exe = tmp_path / "merge_c_abi_host"
+    cmd = ["gcc", "-std=c11", "-O2", "-DHM_HOST_BUILD", str(root / "examples" / "merge_c_abi.c"), f"-I{root / 'include'}", f"-L{lib}", "-lhdrmerge_host",
+           f"-Wl,-rpath,{lib}", "-lm", "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI merge OK" in r.stdout and "on host" in r.stdout
