@@ -138,6 +138,9 @@ class SharedHostImage:
         import torch.distributed as dist
         nbytes = 8 * int(np.prod(shape, dtype=np.int64)) * (2 if with_std else 1)
         collective = world_size > 1 or (group is not None)
+        if collective and group is None and dist.get_backend() == "nccl":
+            raise ValueError("SharedHostImage.open exchanges host tensors: pass a CPU process group (dist.new_group(backend='gloo')) "
+                             "when the default group is nccl")
         name, mm = None, None
         if rank == dst and nbytes > 0:
             name = f"hm_image_{os.getpid()}_{secrets.token_hex(6)}"
