@@ -1311,3 +1311,43 @@ def test_merge_more_than_32_frames(eng, n, with_std, f64):
     close(host(out["val"]), ref["val_ff"], F64_RTOL if f64 else VAL_RTOL)
     if with_std:
         close(host(out["std"]), ref["std_ff"], STD_RTOL)
+
+
+# ------------------------------------------------------------------ the two builds of the C ABI against each other
+@pytest.mark.parametrize("n,with_std,corr", [(3, False, False), (7, True, False), (7, True, True), (15, False, True), (20, True, True)])
+def test_host_build_and_device_build_agree(eng, n, with_std, corr):
+    """libhdrmerge_host.so (plain C++) and libhdrmerge.so (HIP) are two from-scratch builds of one ABI with one operation sequence per
+    element: on uint8 stacks - tables from the host, IEEE division / sqrt, fma in frame order on both sides - they give the SAME BITS, with
+    dark maps (hot-pixel medians) and a flat field too. (float64 frames evaluate exp() in two different math libraries: 1e-12.)"""
+    from camera_linearity_amd.measurand import _HOST_ENGINE as heng
+    h, w = 45, 38
+    frames, stds, t = orc.synthetic_stack(300 + n, n, h, w, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    rng = np.random.default_rng(n)
+    kw_h, kw_d = {}, {}
+    if corr:
+        dark = (rng.random((h, w, 3)) < 0.03).astype(np.uint8) * 210
+        flat = rng.integers(170, 235, size=(h, w, 3)).astype(np.uint8)
+        fstd = np.full((h, w, 3), 0.002)
+        dk = [dark if i % 2 else None for i in range(n)]
+        common = dict(dark_min=[90 if i % 2 else 256 for i in range(n)], median_k=3, ff_mean=[0.8, 0.79, 0.81])
+        if with_std:
+            common.update(ff_std_mean=[0.002] * 3)
+        kw_h = dict(darks=[None if d is None else torch.from_numpy(d) for d in dk], flat=torch.from_numpy(flat), **common)
+        kw_d = dict(darks=[None if d is None else dev(d) for d in dk], flat=dev(flat), **common)
+        if with_std:
+            kw_h.update(flat_std=torch.from_numpy(fstd))
+            kw_d.update(flat_std=dev(fstd))
+    sd_h = [torch.from_numpy(s_) for s_ in stds] if with_std else None
+    sd_d = [dev(s_) for s_ in stds] if with_std else None
+    host = heng.merge([torch.from_numpy(f) for f in frames], t, icrf, diff if with_std else None, sd_h, want_sum_w=True, **kw_h)
+    devo = eng.merge([dev(f) for f in frames], t, icrf, diff if with_std else None, sd_d, want_sum_w=True, **kw_d)
+    for key in host:
+        assert np.array_equal(host[key].numpy(), devo[key].cpu().numpy()), key
+    # float64 frames
+    f64 = [orc.unit_from_u8(f) + (rng.random(f.shape) - 0.5) * 1e-3 for f in frames]
+    host = heng.merge([torch.from_numpy(f) for f in f64], t, icrf, diff if with_std else None, sd_h)
+    devo = eng.merge([dev(f) for f in f64], t, icrf, diff if with_std else None, sd_d)
+    close(devo["val"].cpu().numpy(), host["val"].numpy(), 1e-12)
+    if with_std:
+        close(devo["std"].cpu().numpy(), host["std"].numpy(), STD_RTOL)
