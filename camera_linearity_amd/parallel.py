@@ -180,6 +180,12 @@ class SharedHostImage:
             return self.pinned
         rc = torch.cuda.cudart().cudaHostRegister(self.val.data_ptr(), self.nbytes, 0)
         self.pinned = int(rc) == 0
+        if not self.pinned:                                  # do not leave the refusal behind as the runtime's sticky "last error"
+            try:
+                import ctypes
+                ctypes.CDLL("libamdhip64.so").hipGetLastError()
+            except OSError:
+                pass
         return self.pinned
 
     def close(self) -> None:
