@@ -131,6 +131,19 @@ __device__ __forceinline__ double rsqrt_third_order(double q) {
     return __builtin_amdgcn_class(y0, 0x264) ? y0 : y;                  // -inf | -0 | +0 | +inf
 }
 
+// 1 / x for the per-(pixel, frame) reciprocals of the pixel-major kernel: the hardware estimate and ONE second-order step, r0 (1 + e + e^2)
+// with e = 1 - x r0 - 4 instructions and at most 1.00 ulp (hm_stats.hip: rcp_newton, checked on 2 M operands) where the IEEE division
+// expansion costs eleven, two of them quarter-rate; x = 0 / inf / NaN keep the estimate (inf / 0 / NaN, the IEEE answers).
+#ifndef HM_ENERGY_RCP
+#define HM_ENERGY_RCP 1
+#endif
+__device__ __forceinline__ double rcp_second_order(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    const double r = fma(r0, fma(e, e, e), r0);
+    return __builtin_amdgcn_class(r0, 0x264) ? r0 : r;                   // -inf | -0 | +0 | +inf
+}
+
 template <int N, bool STD>
 __global__ __launch_bounds__(256) void k_energy_pixel(const EnergyK a, const EnergyPairs pr) {
     constexpr int P = N * (N - 1) / 2;
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256) void k_energy_pixel(const EnergyK a, const Ene
             double x = lut[q[i]];
             if (x < lo || x > hi) x = __builtin_nan("");                       // :96-97
             v[i] = x;
-            rv[i] = 1.0 / x;
+            rv[i] = HM_ENERGY_RCP ? rcp_second_order(x) : 1.0 / x;
             s[i] = STD ? a.sd[px * N + i] : 0.0;
         }
         int p = 0;
