@@ -462,6 +462,64 @@ def merge(frames, exposures, icrf, icrf_diff=None, stds=None, **kw) -> dict:
     return plan.outputs
 
 
+class PlanGraph:
+    """A sequence of merge plans recorded ONCE into a hipGraph and replayed with one host call.
+
+    The library makes no synchronising call, allocates nothing and copies nothing (every entry point only enqueues kernels on the stream it
+    is given; workspaces are the caller's), so whatever `MergePlan.launch()` enqueues - the streaming kernel, the dark-map scan and patch,
+    the launches of a chunked stack - is capturable as it is. What a graph saves is host time: ~6 us of ctypes + argument checking +
+    kernel-argument packing per hm_merge call, which is the whole cost of a small stack (BASELINE config 1, 3 x 256 x 256 x 3: the kernel
+    runs for ~3 us). Streams of LARGE stacks gain nothing (the device is busy for longer than the host needs to enqueue the next launch).
+
+    The graph holds the plans (and through them every tensor the recorded kernels read or write): inputs are refreshed by copying into
+    the plans' frame tensors (`frames[i].copy_(...)`), outputs are read from `plans[i].outputs` after `replay()`.
+    """
+
+    def __init__(self, plans: Sequence[MergePlan], warmup: bool = True, lanes: int = 1):
+        """lanes > 1: the plans are dealt round-robin onto `lanes` parallel branches of the graph (forked from and joined to the capture
+        stream), so that kernels too small to fill 256 CUs overlap; the plans must then be independent of each other (no plan reads what
+        another writes)."""
+        plans = list(plans)
+        if not plans:
+            raise ValueError("PlanGraph needs at least one plan")
+        if any(p.host for p in plans):
+            raise TypeError("PlanGraph records device launches; host-backend plans run synchronously in launch()")
+        dev = plans[0].device
+        if any(p.device != dev for p in plans):
+            raise ValueError("all plans of a graph must live on one device")
+        if lanes < 1:
+            raise ValueError("lanes must be >= 1")
+        self.plans = plans
+        self.device = dev
+        self.lanes = min(int(lanes), len(plans))
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream(dev)
+            branches = [torch.cuda.Stream(dev) for _ in range(self.lanes - 1)]
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                if warmup:                      # first launches query the kernels' occupancy and load their code objects: outside the capture
+                    for p in plans:
+                        p.launch()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=side):
+                    for b in branches:          # fork
+                        b.wait_stream(side)
+                    for i, p in enumerate(plans):
+                        lane = i % self.lanes
+                        p.launch(side.cuda_stream if lane == 0 else branches[lane - 1].cuda_stream)
+                    for b in branches:          # join
+                        side.wait_stream(b)
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+    def replay(self) -> None:
+        """Enqueue the recorded launches on the current stream of the graph's device."""
+        if torch.cuda.current_device() == self.device.index:
+            self.graph.replay()
+        else:
+            with torch.cuda.device(self.device):
+                self.graph.replay()
+
+
 def sum_of_weights(frames, darks=None, dark_min=None, median_k: int = 3, **kw):
     """modules/exposure_series.py:317-345 -> (S, S**2) as device tensors."""
     Cc = frames[0].shape[-1]

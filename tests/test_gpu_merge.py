@@ -1351,3 +1351,60 @@ def test_host_build_and_device_build_agree(eng, n, with_std, corr):
     close(devo["val"].cpu().numpy(), host["val"].numpy(), 1e-12)
     if with_std:
         close(devo["std"].cpu().numpy(), host["std"].numpy(), STD_RTOL)
+
+
+def test_plan_graph_replays_every_launch_bit_identically(eng):
+    """engine.PlanGraph: plans of every launch shape (one streaming kernel; streaming + dark-map scan + patch; the chunked launches of a
+    40-frame stack; a run-time-N stack with std and flat field) recorded into ONE hipGraph. A replay must reproduce the directly launched
+    outputs bit for bit - also after the inputs were overwritten in place (the graph reads the tensors, not a snapshot of them)."""
+    rng = np.random.default_rng(77)
+    icrf, diff = orc.synthetic_icrf()
+    plans, inputs = [], []
+    # config-1-sized val-only stacks
+    for seed in range(4):
+        frames, _, t = orc.synthetic_stack(300 + seed, 3, 64, 48)
+        fd = [dev(f) for f in frames]
+        plans.append(eng.plan_merge(fd, t, icrf)); inputs.append(fd)
+    # std + dark maps + flat field (three kernels per launch())
+    frames, stds, t = orc.synthetic_stack(310, 7, 40, 36, with_std=True)
+    d = rng.integers(0, 10, size=(40, 36, 3)).astype(np.uint8); d[rng.random(d.shape) < 0.02] = 210
+    flat = rng.integers(150, 240, (40, 36, 3)).astype(np.uint8)
+    fd = [dev(f) for f in frames]
+    plans.append(eng.plan_merge(fd, t, icrf, diff, [dev(s) for s in stds], darks=[dev(d)] * 7, dark_min=[100] * 7, median_k=3,
+                                flat=dev(flat), flat_std=dev(np.full(flat.shape, 0.002)), ff_mean=[0.8, 0.81, 0.79], ff_std_mean=[0.002] * 3))
+    inputs.append(fd)
+    # 40 frames: two chunked launches; 20 frames with std: the run-time-N kernel
+    for n, with_std in ((40, False), (20, True)):
+        frames, stds, t = orc.synthetic_stack(320 + n, n, 24, 32, with_std=with_std)
+        fd = [dev(f) for f in frames]
+        plans.append(eng.plan_merge(fd, t, icrf, diff if with_std else None, [dev(s) for s in stds] if with_std else None)); inputs.append(fd)
+    graph = eng.PlanGraph(plans)
+    wide = eng.PlanGraph(plans, lanes=3)               # the same launches on three parallel branches
+
+    def direct():
+        for p in plans:
+            p.launch()
+        torch.cuda.synchronize()
+        return [{k: v.clone() for k, v in p.outputs.items()} for p in plans]
+
+    def replayed(g):
+        for p in plans:
+            for v in p.outputs.values():
+                v.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        return [{k: v.clone() for k, v in p.outputs.items()} for p in plans]
+
+    for round_ in range(2):
+        want = direct()
+        for g in (graph, wide):
+            for i, (a_, b_) in enumerate(zip(want, replayed(g))):
+                assert a_.keys() == b_.keys()
+                for key in a_:
+                    assert torch.equal(a_[key], b_[key]), (round_, g.lanes, i, key)
+                    assert not torch.isnan(b_[key]).any() or torch.isnan(a_[key]).any()
+        for fd in inputs:                                   # new image data in the same tensors
+            for f in fd:
+                f.copy_(torch.flip(f, dims=(1,)))
+    with pytest.raises(ValueError):
+        eng.PlanGraph([])

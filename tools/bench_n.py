@@ -14,8 +14,10 @@ from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icr
 dev = torch.device("cuda:0")
 icrf, diff = synthetic_icrf()
 H, W = 2048, 4096
-ns = [int(x) for x in sys.argv[1:]] or [4, 8, 12, 16, 17, 24, 32]
-for with_std in (False, True):
+args = [x for x in sys.argv[1:] if not x.startswith("--")]
+ns = [int(x) for x in args] or [4, 8, 12, 16, 17, 24, 32]
+modes = (False,) if "--val-only" in sys.argv else (True,) if "--std-only" in sys.argv else (False, True)
+for with_std in modes:
     for n in ns:
         frames, stds, t = synthetic_stack_device(3, n, H, W, device=dev, with_std=with_std)
         plan = engine.plan_merge(frames, t, icrf, diff if with_std else None, stds)
