@@ -823,3 +823,17 @@ def test_dimension_statistics_all_nan_column_and_errors(M):
     assert np.isnan(m[2, 1]) and np.all(m[np.isfinite(m)] == 1.0) and np.isnan(got["std"].cpu().numpy()[2, 1])
     with pytest.raises(ValueError):
         M(a).compute_dimension_statistics(axis=3)
+
+
+def test_device_and_host_builds_agree_on_random_cases():
+    """tools/fuzz_backends.py for 12 seconds (~10 000 random cases over merge, operators, statistics, thresholds / differences, linearize,
+    corrections, histogram / extract): the HIP library against the independent host build of the same ABI - bit-exact where the operation
+    sequence is shared (uint8 merges with every correction, gathers, filters), to rounding where two math libraries meet."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_backends.py"), "--seconds", "12", "--seed", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 failures" in r.stdout

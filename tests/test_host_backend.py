@@ -5,6 +5,8 @@ nothing from oracle/). CPU tests: they run without a GPU and never touch the HIP
 Pinned like the HIP path: against the reference-generated golden vectors (tests/golden/*.npz) and the NumPy oracle, same
 tolerances (index exact; val 1e-12 uint8 / 1e-11 float64 frames; std 1e-9; statistics 1e-11). BASELINE.json configs[0] - "3-frame
 256x256x3 uint8 synthetic stack, identity ICRF, NumPy Measurand CPU merge (plumbing, no GPU)" - runs literally here."""
+import pathlib
+
 import numpy as np
 import pytest
 
@@ -275,3 +277,15 @@ def test_c_abi_example_host_build(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C ABI merge OK" in r.stdout and "on host" in r.stdout
+
+
+def test_fuzz_tool_self_check():
+    """tools/fuzz_backends.py (device build against host build on random cases; the GPU suite runs it for real) stays runnable: host
+    build against itself for three seconds."""
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "fuzz_backends.py"), "--self-check", "--seconds", "3", "--seed", "5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 failures" in r.stdout

@@ -1,0 +1,399 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the two independent builds of the C ABI: the HIP library on the MI355X against the from-scratch host build
+(csrc_host/hm_host.cpp), through the same Python layer (Measurand(use_cupy=GPU) vs Measurand(use_cupy=False), engine vs host engine),
+on random shapes, channel counts, frame counts, operand combinations. Neither implementation shares code with the other (nor with the
+NumPy oracle), so agreement on thousands of random cases is evidence that is independent of tests/.
+
+    python tools/fuzz_backends.py [--seconds 120] [--seed 1] [--log gpurun_out/fuzz.log]
+
+Expectation per case: `exact` (integer / gather / shared-operation-sequence results: merge of uint8 frames, linearize, thresholds, extract,
+histogram counts, hot-pixel filter) or `rtol` (transcendental or reduction-order dependent results). Prints one line per failing case
+(with the arguments to reproduce it), a progress line every 10 s and a summary; exit code 1 if anything failed."""
+import argparse
+import pathlib
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from camera_linearity_amd import engine, settings  # noqa: E402
+from camera_linearity_amd.measurand import _HOST_ENGINE as heng  # noqa: E402
+from camera_linearity_amd.measurand_factory import Measurand  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--log", default=None)
+ap.add_argument("--self-check", action="store_true", help="host build against itself (no GPU): exercises this script only")
+args = ap.parse_args()
+dev = torch.device("cpu" if args.self_check else "cuda:0")
+if args.self_check:
+    engine = heng
+master = np.random.default_rng(args.seed)
+log = open(args.log, "w") if args.log else None
+
+
+def say(*a):
+    line = " ".join(str(x) for x in a)
+    print(line, flush=True)
+    if log:
+        log.write(line + "\n"); log.flush()
+
+
+def D(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x).copy()).to(dev)
+
+
+GPU = not args.self_check                                              # Measurand(use_cupy=GPU): the device class, or the host class in --self-check
+
+
+def Hh(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x).copy())
+
+
+def as_np(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+class Mismatch(Exception):
+    pass
+
+
+def compare(what, a, b, rtol, atol=0.0):
+    """a: device result, b: host result. rtol None = bit-exact (NaN positions must agree). atol: absolute slack (statistics of nearly
+    constant data: a standard deviation of exactly 0 against one of an ulp of the DATA)."""
+    a, b = as_np(a), as_np(b)
+    if (a is None) != (b is None):
+        raise Mismatch(f"{what}: one side is None")
+    if a is None:
+        return 0.0
+    if a.shape != b.shape:
+        raise Mismatch(f"{what}: shapes {a.shape} vs {b.shape}")
+    if a.dtype.kind in "iub" or rtol is None:
+        if not np.array_equal(a, b, equal_nan=a.dtype.kind == "f"):
+            bad = np.flatnonzero(~((a == b) | ((a != a) & (b != b))).ravel()) if a.dtype.kind == "f" else np.flatnonzero((a != b).ravel())
+            i = int(bad[0])
+            raise Mismatch(f"{what}: {bad.size} of {a.size} elements differ, first at flat index {i}: {a.ravel()[i]!r} vs {b.ravel()[i]!r}")
+        return 0.0
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        raise Mismatch(f"{what}: NaN positions differ ({int(na.sum())} vs {int(nb.sum())})")
+    ia, ib = np.isinf(a), np.isinf(b)
+    if not np.array_equal(ia, ib) or not np.array_equal(a[ia], b[ib]):
+        raise Mismatch(f"{what}: infinities differ")
+    ok = ~(na | ia)
+    if not ok.any():
+        return 0.0
+    den = np.maximum(np.abs(b[ok]), np.finfo(np.float64).tiny)
+    err = float(np.max(np.abs(a[ok] - b[ok]) / den))
+    scale = float(np.max(np.abs(b[ok]))) if ok.any() else 0.0
+    absd = float(np.max(np.abs(a[ok] - b[ok])))
+    if err > rtol and absd > max(rtol * scale * 1e-3, atol):          # cancellation near zero: judged against the array's scale
+        i = int(np.argmax(np.abs(a[ok] - b[ok]) / den))
+        raise Mismatch(f"{what}: max rel err {err:.3e} (abs {absd:.3e}, scale {scale:.3e}) > {rtol:g}; {a[ok][i]!r} vs {b[ok][i]!r}")
+    return err
+
+
+# ------------------------------------------------------------------------------------------------ case generators
+def icrf_tables(rng, c):
+    g = np.linspace(0, 1, 256)[:, None] ** rng.uniform(0.6, 2.6, size=c)[None, :]
+    if rng.random() < 0.2:
+        g = g - 0.1                                                    # negative radiances, zero crossing
+    d = np.stack([np.gradient(g[:, k], 2 / 255) for k in range(c)], axis=1)
+    return np.ascontiguousarray(g), np.ascontiguousarray(d)
+
+
+def case_merge(rng):
+    c = int(rng.choice([1, 2, 3, 3, 3, 4]))
+    n = int(rng.choice([1, 2, 3, 5, 7, 7, 8, 9, 15, 16, 17, 20, 32, 33, 40]))
+    h, w = int(rng.integers(1, 48)), int(rng.integers(1, 130))
+    if rng.random() < 0.3:                                             # whole 128-element groups: the streaming kernels, not only the generic tail
+        h, w = int(rng.integers(8, 40)), 128 * int(rng.integers(1, 4))
+    f64 = rng.random() < 0.25
+    with_std = rng.random() < 0.5
+    use_dark = rng.random() < 0.4
+    use_flat = rng.random() < 0.4
+    sum_w = rng.random() < 0.3
+    k = int(rng.choice([3, 5]))
+    desc = f"merge n={n} h={h} w={w} c={c} f64={f64} std={with_std} dark={use_dark} flat={use_flat} sum_w={sum_w} k={k}"
+    t = np.sort(rng.uniform(1e-4, 2.0, size=n))
+    if f64:
+        frames = [rng.random((h, w, c)) * rng.choice([1.0, 1.2]) for _ in range(n)]
+    else:
+        frames = [rng.integers(0, 256, (h, w, c)).astype(np.uint8) for _ in range(n)]
+    stds = [0.004 * (1 + rng.random((h, w, c))) for _ in range(n)] if with_std else None
+    g, d = icrf_tables(rng, c)
+    kw = {}
+    if use_dark:
+        darks, mins = [], []
+        for i in range(n):
+            if rng.random() < 0.3:
+                darks.append(None); mins.append(256)
+            else:
+                dm = rng.integers(0, 20, (h, w, c)).astype(np.uint8)
+                dm[rng.random(dm.shape) < rng.choice([0.001, 0.02, 0.2])] = 220
+                darks.append(dm); mins.append(int(rng.choice([100, 221, 15])))
+        if any(x is not None for x in darks):
+            kw.update(darks=darks, dark_min=mins, median_k=k, hot_queue=bool(rng.random() < 0.7))
+    if use_flat:
+        if rng.random() < 0.6:
+            flat = rng.integers(120, 250, (h, w, c)).astype(np.uint8)
+        else:
+            flat = 0.5 + 0.5 * rng.random((h, w, c))
+        kw.update(flat=flat, ff_mean=list(rng.uniform(0.6, 0.9, size=c)))
+        if with_std:
+            kw.update(flat_std=0.002 * (1 + rng.random((h, w, c))), ff_std_mean=list(rng.uniform(0.001, 0.003, size=c)))
+    kw["want_sum_w"] = bool(sum_w)
+
+    def run(eng, conv):
+        k2 = dict(kw)
+        for name in ("flat", "flat_std"):
+            if name in k2:
+                k2[name] = conv(k2[name])
+        if "darks" in k2:
+            k2["darks"] = [conv(x) for x in k2["darks"]]
+        return eng.merge([conv(f) for f in frames], list(t), g, d if with_std else None, [conv(s) for s in stds] if with_std else None, **k2)
+
+    a, b = run(engine, D), run(heng, Hh)
+    exact = not f64                                                    # float64 frames evaluate exp(): two math libraries
+    for key in b:                                                      # (the std of float64 frames amplifies exp()'s last bit through (dw g + w dg)/S - dw w g/S^2)
+        compare(f"{key}", a[key], b[key], None if exact else (1e-9 if key == "std" else 1e-12))
+    return desc
+
+
+def rand_operand(rng, shape, positive=False):
+    v = rng.normal(size=shape) * 10 ** rng.uniform(-2, 2)
+    if positive:
+        v = np.abs(v) + 0.1
+    s = np.abs(rng.normal(size=shape)) * 0.05 if rng.random() < 0.6 else None
+    return v, s
+
+
+def bshapes(rng):
+    nd = int(rng.integers(1, 5))
+    full = [int(rng.integers(1, 9)) for _ in range(nd)]
+    if rng.random() < 0.3:
+        full[-1] = int(rng.choice([64, 128, 300]))
+    a, b = list(full), list(full)
+    for dd in range(nd):
+        r = rng.random()
+        if r < 0.2:
+            a[dd] = 1
+        elif r < 0.4:
+            b[dd] = 1
+    if rng.random() < 0.3:
+        b = b[int(rng.integers(0, nd)):] or [1]
+    return tuple(a), tuple(b)
+
+
+def case_binary(rng):
+    sa, sb = bshapes(rng)
+    op = str(rng.choice(["add", "sub", "mul", "div", "pow"]))
+    x, xs = rand_operand(rng, sa, positive=(op == "pow"))
+    y, ys = rand_operand(rng, sb, positive=(op == "div"))
+    if op == "pow":
+        y = rng.uniform(-2, 3, size=sb)
+    desc = f"binary {op} {sa} {sb} std=({xs is not None},{ys is not None})"
+    fn = {"add": lambda p, q: p + q, "sub": lambda p, q: p - q, "mul": lambda p, q: p * q, "div": lambda p, q: p / q, "pow": lambda p, q: p ** q}[op]
+    ra = fn(Measurand(D(x), D(xs), use_cupy=GPU), Measurand(D(y), D(ys), use_cupy=GPU))
+    rb = fn(Measurand(x.copy(), None if xs is None else xs.copy(), use_cupy=False), Measurand(y.copy(), None if ys is None else ys.copy(), use_cupy=False))
+    rt = 1e-12 if op == "pow" else 1e-14
+    compare("val", ra.val, rb.val, None if op in ("add", "sub", "mul", "div") else rt)
+    compare("std", ra.std, rb.std, rt)
+    return desc
+
+
+def case_unary(rng):
+    shape = tuple(int(rng.integers(1, 40)) for _ in range(int(rng.integers(1, 4))))
+    op = str(rng.choice(["neg", "log_e", "log_10"]))
+    x, xs = rand_operand(rng, shape, positive=(op != "neg"))
+    fn = {"neg": lambda m: -m, "log_e": lambda m: m.log_e(), "log_10": lambda m: m.log_10()}[op]
+    ra = fn(Measurand(D(x), D(xs), use_cupy=GPU))
+    rb = fn(Measurand(x.copy(), None if xs is None else xs.copy(), use_cupy=False))
+    compare("val", ra.val, rb.val, None if op == "neg" else 1e-14)
+    compare("std", ra.std, rb.std, 1e-14)
+    return f"unary {op} {shape}"
+
+
+def case_stats(rng):
+    nd = int(rng.integers(1, 5))
+    shape = tuple(int(rng.integers(1, 24)) for _ in range(nd))
+    if rng.random() < 0.3:
+        shape = shape[:-1] + (int(rng.choice([3, 3, 1, 4])),)
+    x = rng.normal(size=shape) * 3 + rng.uniform(-100, 100)
+    x[rng.random(shape) < rng.choice([0.0, 0.1, 0.6])] = np.nan
+    xs = np.abs(rng.normal(size=shape)) * 0.1 + 0.01 if rng.random() < 0.5 else None
+    r = rng.random()
+    if r < 0.2:
+        axis = None
+    elif r < 0.6 or nd == 1:
+        axis = int(rng.integers(-nd, nd))
+    else:
+        kk = int(rng.integers(1, nd + 1))
+        axis = tuple(int(a) for a in rng.choice(nd, size=kk, replace=False))
+    desc = f"stats shape={shape} axis={axis} weighted={xs is not None}"
+    if xs is not None and axis is not None:
+        ax = (axis,) if isinstance(axis, int) else axis
+        if sorted(a % nd for a in ax) != list(range(nd - 1)) and sorted(a % nd for a in ax) != list(range(len(ax))):
+            pass                                                       # the package defines every axis choice (keepdims mean), both builds must agree
+    ra = Measurand(D(x), D(xs), use_cupy=GPU).compute_dimension_statistics(axis)
+    rb = Measurand(x.copy(), None if xs is None else xs.copy(), use_cupy=False).compute_dimension_statistics(axis)
+    assert ra.keys() == rb.keys(), (ra.keys(), rb.keys())
+    mag = float(np.nanmax(np.abs(x))) if np.isfinite(x).any() else 0.0
+    for key in rb:
+        compare(key, ra[key], rb[key], 1e-9 if "std" in key or "err" in key else 1e-11, atol=1e-13 * mag)
+    return desc
+
+
+def case_pair(rng):
+    sa, sb = bshapes(rng)
+    if rng.random() < 0.5:
+        sb = sa
+    c = sa[-1]
+    x, xs = rand_operand(rng, sa, positive=True)
+    y, ys = rand_operand(rng, sb, positive=True)
+    if rng.random() < 0.5:
+        ys = None if xs is None else np.abs(rng.normal(size=sb)) * 0.05
+        if xs is None:
+            ys = None
+    mult = float(rng.uniform(0.1, 8))
+    lo = [float(rng.uniform(0, 0.5)) if rng.random() < 0.7 else None for _ in range(c)]
+    hi = [float(rng.uniform(5, 50)) if rng.random() < 0.7 else None for _ in range(c)]
+    desc = f"thresholds+difference+interpolate {sa} {sb} std=({xs is not None},{ys is not None})"
+    out = []
+    for cupy in (GPU, False):
+        conv = D if cupy else (lambda v: None if v is None else v.copy())
+        A, B = Measurand(conv(x), conv(xs), use_cupy=cupy), Measurand(conv(y), conv(ys), use_cupy=cupy)
+        if c <= 32:
+            A.apply_thresholds(lo, hi)
+        ad, rd = type(A).compute_difference(A, B, mult)
+        it = type(A).interpolate(A, B, 1.0, 3.0, 1.7)
+        out.append((A.val, A.std, ad.val, ad.std, rd.val, rd.std, it.val, it.std))
+    names = ("thr.val", "thr.std", "abs.val", "abs.std", "rel.val", "rel.std", "interp.val", "interp.std")
+    for nm, a, b in zip(names, *out):
+        compare(nm, a, b, None if nm.startswith("thr") else 1e-13)
+    return desc
+
+
+def case_linearize(rng):
+    c = int(rng.choice([1, 2, 3, 4]))
+    shape = tuple(int(rng.integers(1, 40)) for _ in range(int(rng.integers(1, 3)))) + (c,)
+    g, d = icrf_tables(rng, c)
+    one_d = c == 1 and rng.random() < 0.5
+    if one_d:
+        g, d = g[:, 0].copy(), d[:, 0].copy()
+    u8 = rng.random() < 0.5
+    x = rng.integers(0, 256, shape).astype(np.uint8) if u8 else rng.uniform(-0.3, 1.4, size=shape)
+    if not u8 and rng.random() < 0.5:
+        x = (np.round(x * 255) + rng.choice([0.0, 0.5], size=shape)) / 255          # .5 ties
+    xs = np.abs(rng.normal(size=shape)) * 0.01 if rng.random() < 0.6 else None
+    use_diff = rng.random() < 0.7
+    desc = f"linearize shape={shape} u8={u8} 1d={one_d} std={xs is not None} diff={use_diff}"
+    ra = engine.linearize(D(x), D(xs), g, d if use_diff else None, return_index=True)
+    rb = heng.linearize(Hh(x), Hh(xs), g, d if use_diff else None, return_index=True)
+    compare("idx", ra[2], rb[2], None)
+    compare("val", ra[0], rb[0], None)
+    compare("std", ra[1], rb[1], None)
+    wa, wb = engine.gaussian_weight(D(x)), heng.gaussian_weight(Hh(x))
+    compare("w", wa[0], wb[0], None if u8 else 1e-14)
+    compare("dw", wa[1], wb[1], None if u8 else 1e-14)
+    return desc
+
+
+def case_corrections(rng):
+    c = int(rng.choice([1, 3, 3, 4]))
+    h, w = int(rng.integers(5, 60)), int(rng.integers(5, 60))               # (an ROI of floor(size * p) >= 1 rows and columns)
+    k = int(rng.choice([3, 5, 7]))
+    u8 = rng.random() < 0.5
+    x = rng.integers(0, 256, (h, w, c)).astype(np.uint8) if u8 else rng.random((h, w, c))
+    dm = rng.integers(0, 30, (h, w, c)).astype(np.uint8)
+    dm[rng.random(dm.shape) < rng.choice([0.0, 0.01, 0.3])] = 230
+    if rng.random() < 0.5:
+        dmap, thr = dm, 0.5
+    else:
+        dmap, thr = dm.astype(np.float64) / 255 * 1.5, 0.6
+    desc = f"hot_pixel_filter+normalize {h}x{w}x{c} k={k} u8={u8} map={'u8' if dmap.dtype == np.uint8 else 'f64'}"
+    fa = engine.hot_pixel_filter(D(x), D(dmap), thr, k)
+    fb = heng.hot_pixel_filter(Hh(x), Hh(dmap), thr, k)
+    compare("filtered", fa, fb, None)
+    val = rng.random((h, w, c)) * 4
+    sd = np.abs(rng.normal(size=(h, w, c))) * 0.01 if rng.random() < 0.6 else None
+    flat = rng.integers(100, 250, (h, w, c)).astype(np.uint8) if rng.random() < 0.5 else 0.4 + 0.6 * rng.random((h, w, c))
+    fstd = 0.002 * (1 + rng.random((h, w, c))) if sd is not None else None
+    x0, x1, y0, y1 = engine.flat_roi_bounds(h, w, float(rng.uniform(0.2, 1.0)))
+    ma, mb = engine.roi_mean(D(flat), x0, x1, y0, y1), heng.roi_mean(Hh(flat), x0, x1, y0, y1)
+    compare("roi_mean", ma, mb, 1e-13)
+    m = as_np(mb)
+    sm = list(rng.uniform(0.001, 0.003, size=c)) if sd is not None else None
+    na = engine.normalize_by_map(D(val), D(sd), D(flat), D(fstd), m, sm)
+    nb = heng.normalize_by_map(Hh(val), Hh(sd), Hh(flat), Hh(fstd), m, sm)
+    compare("norm.val", na[0], nb[0], None)
+    compare("norm.std", na[1], nb[1], 1e-14)
+    return desc
+
+
+def case_hist_extract(rng):
+    c = int(rng.choice([1, 2, 3, 4]))
+    shape = (int(rng.integers(1, 50)), int(rng.integers(1, 50)), c)
+    x = rng.random(shape) * 1.2 - 0.1
+    x[rng.random(shape) < 0.05] = np.nan
+    xs = np.abs(rng.normal(size=shape)) * 0.01
+    bins = int(rng.choice([4, 16, 100, 256]))
+    rngs = None if rng.random() < 0.3 else (float(rng.uniform(-0.1, 0.3)), float(rng.uniform(0.6, 1.2)))
+    chans = sorted(int(a) for a in rng.choice(c, size=int(rng.integers(1, c + 1)), replace=False))
+    use_std = bool(rng.random() < 0.5)
+    desc = f"histogram+extract {shape} bins={bins} range={rngs} channels={chans} use_std={use_std}"
+    A, B = Measurand(D(x), D(xs), use_cupy=GPU), Measurand(x.copy(), xs.copy(), use_cupy=False)
+    if rngs is not None or not np.isnan(x).any():
+        ha, hb = A.compute_channel_histogram(bins, rngs, chans, use_std), B.compute_channel_histogram(bins, rngs, chans, use_std)
+        assert ha.keys() == hb.keys()
+        for key in hb:
+            va, vb = ha[key], hb[key]
+            if isinstance(vb, (tuple, list)):
+                for i, (pa, pb) in enumerate(zip(va, vb)):
+                    compare(f"hist[{key}][{i}]", pa, pb, 1e-14)
+            else:
+                compare(f"hist[{key}]", va, vb, 1e-14)
+    axis = None if rng.random() < 0.2 else int(rng.integers(-3, 3))
+    n_ax = x.size if axis is None else shape[axis]
+    dims = [int(a) for a in rng.integers(-n_ax, n_ax, size=int(rng.integers(1, 5)))]
+    ea, eb = A.extract(dims, axis), B.extract(dims, axis)
+    compare("extract.val", ea.val, eb.val, None)
+    compare("extract.std", ea.std, eb.std, None)
+    return desc
+
+
+CASES = [(case_merge, 5), (case_binary, 3), (case_unary, 1), (case_stats, 3), (case_pair, 2), (case_linearize, 2), (case_corrections, 2),
+         (case_hist_extract, 2)]
+weights = np.array([w for _, w in CASES], dtype=np.float64)
+weights /= weights.sum()
+counts = {fn.__name__: 0 for fn, _ in CASES}
+fails = 0
+t_end = time.time() + args.seconds
+t_say = time.time() + 10
+i = 0
+settings.configure() if hasattr(settings, "configure") else None
+while time.time() < t_end:
+    seed = int(master.integers(0, 2 ** 62))
+    fn = CASES[int(master.choice(len(CASES), p=weights))][0]
+    try:
+        fn(np.random.default_rng(seed))
+        counts[fn.__name__] += 1
+    except Mismatch as e:
+        fails += 1
+        say(f"FAIL {fn.__name__} seed={seed}: {e}")
+    except Exception as e:                                              # an exception on ONE side only is a finding too; on both sides it is the API's answer
+        fails += 1
+        say(f"ERROR {fn.__name__} seed={seed}: {type(e).__name__}: {e}")
+    i += 1
+    if time.time() > t_say:
+        say(f"... {i} cases, {fails} failures")
+        t_say = time.time() + 10
+say(f"done: {i} cases in {args.seconds:.0f} s, {fails} failures; per generator: {counts}")
+sys.exit(1 if fails else 0)
