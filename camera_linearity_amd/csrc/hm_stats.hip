@@ -244,7 +244,11 @@ __global__ __launch_bounds__(256) void k_interpolate_burst(const double* __restr
 // of its elements (short blocks of shifted sums folded in with Chan's formula, see MomAcc) and thread, wave, workgroup and grid
 // partials are combined with the same pairwise formula in a fixed tree order (bit-reproducible; as stable as the two-pass form:
 // moments are always taken about a mean of the data they cover). NaNs are skipped exactly as np.nansum / np.nanmean do, term by
-// term: `Wall` sums every non-NaN weight (the reference's denominators), the moments take the elements whose v * w is not NaN.
+// term: `Wall` sums every non-NaN weight (the reference's denominators), the moments take the elements whose v * w is FINITE.
+// Infinite terms (a relative difference against y = 0 is one) never enter the moments - inf - K would poison them with NaN where NumPy
+// still answers: their SUM (+inf, -inf, or NaN when both signs occurred) is added into M2, which has no other meaning once a term was
+// infinite, survives every fold and merge there (inf + finite = inf), and mom_finish() then gives NumPy's answers (mean = +-inf / NaN by sign,
+// nanstd = NaN; the weighted formulas' inf or 0) - see there.
 // workgroups of the reduction kernels: 3 per CU. A/B on one box (tools/ab_ops.sh, tools/ab_lin.sh, profiles/r02h_ab_stat_blocks.log): 2040
 // -> 768 takes channel statistics from 0.65 / 0.59 to 0.73 / 0.69 of 8 TB/s and the all-pairs kernel from 1.53 / 2.91 to 1.37 / 2.77 ms
 #ifndef HM_STAT_BLOCKS
@@ -285,17 +289,24 @@ struct MomAcc {
     int cnt;            // acc_add_pair: count of the non-NaN stds as an integer (folded into m.cs by acc_finish)
 };
 __device__ __forceinline__ MomAcc acc_zero() { return MomAcc{mom_zero(), 0.0, 0.0, 0.0, 0.0, false, 0}; }
+// the shift K of a block must be finite (inf - K has to keep its sign): an infinite first element gives +-1e300, and the block it poisons
+// (S1 = +-inf / NaN) is then set aside by acc_fold()
+__device__ __forceinline__ double finite_shift(double v) { return fmin(fmax(v, -1e300), 1e300); }
+__device__ __forceinline__ bool is_finite(double x) { return fabs(x) < __longlong_as_double(0x7ff0000000000000ll); }   // false for NaN and +-inf
 
 __device__ __forceinline__ double rcp_nr(double x);
 // RCP: the two quotients of a fold as products with rcp_nr() (~1 ulp; 14 instructions instead of two IEEE division expansions) - the
 // pair kernels, which are FP64-VALU bound and fold two states per 8 element-pairs
 template <bool RCP = false>
 __device__ __forceinline__ void acc_fold(MomAcc& a) {
-    if (a.S0 != 0.0) {                                              // (a lane whose whole block was skipped: rare, and the only branch)
+    if (!is_finite(a.S1)) {                                         // acc_add_pair let infinite terms in: their sum's class goes to M2, the block is not folded
+        a.m.M2 += a.S1;
+        a.K = 0.0; a.haveK = false;                                 // (K may be the clamped +-1e300 of an infinite first element: take a new one)
+    } else if (a.S0 != 0.0) {                                       // (a lane whose whole block was skipped: rare)
         const double q = RCP ? a.S1 * rcp_nr(a.S0) : a.S1 / a.S0;   // block mean - K
         const double mb = a.K + q;
         const double M2b = a.S2 - a.S1 * q;
-        if (a.m.W == 0.0) { a.m.W = a.S0; a.m.mean = mb; a.m.M2 = M2b; }
+        if (a.m.W == 0.0) { a.m.W = a.S0; a.m.mean = mb; a.m.M2 += M2b; }      // (+= : M2 is 0 here - or already holds infinite terms)
         else {
             const double W = a.m.W + a.S0;
             const double d = mb - a.m.mean;
@@ -319,9 +330,11 @@ __device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s,
         a.m.ss += oks ? s : 0.0;                                            // nanmean(stds)
         a.m.cs += oks ? 1.0 : 0.0;
         const double vw = v * w;
-        use = in_range && (vw == vw);                                       // nansum(values * weights), nansum(weights * (values - mean)**2)
+        use = in_range && is_finite(vw);                                    // nansum(values * weights), nansum(weights * (values - mean)**2)
+        a.m.M2 += (in_range && !use && vw == vw) ? vw : 0.0;                // an infinite term
     } else {
-        use = in_range && (v == v);
+        use = in_range && is_finite(v);
+        a.m.M2 += (in_range && !use && v == v) ? v : 0.0;
         w = 1.0;
     }
     a.K = (!a.haveK && use) ? v : a.K;
@@ -367,6 +380,12 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
     } else {
         use = v == v;
     }
+    // Infinite terms (unweighted: a relative difference against y = 0) are NOT filtered per element here - these kernels are FP64-issue
+    // bound and a second branch per state and element cost 11-21 %, a finiteness test in the first-element path 4 % (profiles/r04n_*,
+    // r04o_*): they enter the block sums (K stays finite - finite_shift() - so S1 becomes +inf / -inf / NaN by their signs) and
+    // acc_fold() moves a non-finite S1 into M2 instead of folding the block. The finite
+    // elements of such a block (at most 63 per lane) are dropped: the mean and the unweighted std are NumPy's regardless; the weighted
+    // std's "inf or 0" (mom_finish) then rests on the finite elements of all other blocks.
     if constexpr (HM_PAIR_EXEC != 0) {
         // EXEC-masked form: the lanes whose element NumPy's nan-functions skip sit out the accumulation (a real branch - the empty volatile asm
         // keeps the compiler from turning it back into selects, which cost 4-6 of the 19 VALU instructions of a state and element; the branch
@@ -374,7 +393,7 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
         if (use) {
             asm volatile("" ::: "memory");
             if constexpr (!LEAN) {
-                if (!a.haveK) { asm volatile("" ::: "memory"); a.K = v; }
+                if (!a.haveK) { asm volatile("" ::: "memory"); a.K = finite_shift(v); }
                 a.haveK = true;
             }
             const double d = v - a.K;
@@ -388,7 +407,7 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
         return;
     }
     if constexpr (!LEAN) {
-        a.K = (!a.haveK && use) ? v : a.K;
+        a.K = (!a.haveK && use) ? finite_shift(v) : a.K;
         a.haveK = a.haveK || use;
     }
     const double d = use ? v - a.K : 0.0;
@@ -405,8 +424,8 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
 __device__ __forceinline__ Mom mom_merge(const Mom& a, const Mom& b) {
     Mom r;
     r.Wall = a.Wall + b.Wall; r.ss = a.ss + b.ss; r.cs = a.cs + b.cs;
-    if (b.W == 0.0) { r.W = a.W; r.mean = a.mean; r.M2 = a.M2; return r; }
-    if (a.W == 0.0) { r.W = b.W; r.mean = b.mean; r.M2 = b.M2; return r; }
+    if (b.W == 0.0) { r.W = a.W; r.mean = a.mean; r.M2 = a.M2 + b.M2; return r; }      // (an empty side's M2 is 0 - or the sum of its infinite terms)
+    if (a.W == 0.0) { r.W = b.W; r.mean = b.mean; r.M2 = b.M2 + a.M2; return r; }
     const double W = a.W + b.W;
     const double d = b.mean - a.mean;
     const double f = b.W / W;
@@ -475,6 +494,18 @@ __device__ __forceinline__ Mom grid_merge(const double* __restrict__ partial, in
 //   mean = nansum(v w) / nansum(w) = W mean_W / Wall;  std = sqrt(nansum(w (v - mean)^2) / nansum(w));  error = nanmean(std)
 __device__ __forceinline__ void mom_finish(const Mom& m, bool weighted, double& mean, double& sd, double& err) {
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (!is_finite(m.M2)) {
+        // a term v * w was infinite; m.M2 is the sum of those terms (+inf, -inf, NaN for both signs). What NumPy then computes:
+        //   nanmean / nansum(v w) / nansum(w): the infinite sum over the count or the weights;  nanstd: (v - mean) is inf - inf = NaN for the
+        //   infinite element and the reduction there is a plain sum -> NaN;  weighted: nansum(w (v - mean)^2) SKIPS the NaN terms - with
+        //   mean = +-inf every finite element with w > 0 contributes inf (sum inf, or 0 when there is none), with mean = NaN every term is
+        //   skipped (sum 0) - over nansum(w).
+        mean = m.M2 / m.Wall;
+        if (!weighted) sd = nan;
+        else sd = sqrt(((mean == mean && m.W > 0.0) ? __longlong_as_double(0x7ff0000000000000ll) : 0.0) / m.Wall);
+        err = weighted ? m.ss / m.cs : nan;
+        return;
+    }
     if (m.Wall == m.W) { mean = m.W == 0.0 ? nan : m.mean; sd = sqrt(m.M2 / m.Wall); }
     else {                                                  // some weights belong to NaN values: the reference's denominators still count them
         mean = (m.W * m.mean) / m.Wall;

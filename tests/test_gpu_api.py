@@ -837,3 +837,65 @@ def test_device_and_host_builds_agree_on_random_cases():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failures" in r.stdout
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_statistics_with_infinite_values_answer_like_numpy(M, weighted):
+    """Infinite values (a relative difference against y = 0 is one): np.nanmean keeps them (+-inf by sign, NaN for both signs), np.nanstd
+    turns NaN, the weighted formulas of modules/measurand.py:342-346 give inf or 0 (their nansum skips the inf - inf terms). The one-pass
+    moments keep infinite terms out (inf - shift would be NaN) and carry their sum separately; every statistics kernel must answer as
+    the NumPy oracle does: all-but-last axes (hm_channel_statistics), other axes (hm_axis_statistics), whole array, and the fused pair
+    kernels against the unfused path."""
+    from camera_linearity_amd import engine
+    rng = np.random.default_rng(42)
+    shape = (37, 29, 4)
+    x = rng.normal(size=shape) + 3.0
+    x[rng.random(shape) < 0.1] = np.nan
+    x[3, 5, 0] = np.inf                        # channel 0: +inf only
+    x[7, 1, 1] = -np.inf                       # channel 1: -inf only
+    x[0, 0, 2] = np.inf; x[36, 28, 2] = -np.inf; x[5, 5, 2] = np.inf      # channel 2: both signs
+    #                                            channel 3: clean
+    s = 0.01 + 0.05 * rng.random(shape) if weighted else None
+    m = M(x, s)
+    with np.errstate(all="ignore"):
+        for axis in ((0, 1), 0, 1, 2, None, (1, 2)):
+            if weighted and axis not in ((0, 1), None, 0):
+                continue                                   # (weighted statistics on other axes: the reference's formula does not broadcast)
+            ref = orc.dimension_statistics(x, s, axis)
+            got = m.compute_dimension_statistics(axis)
+            for key in ("mean", "std"):
+                g, r = got[key].cpu().numpy(), np.asarray(ref[key])
+                assert np.array_equal(np.isnan(g), np.isnan(r)), (axis, key, g, r)
+                assert np.array_equal(np.isinf(g), np.isinf(r)) and np.array_equal(g[np.isinf(g)], r[np.isinf(r)]), (axis, key, g, r)
+                fin = np.isfinite(r)
+                np.testing.assert_allclose(g[fin], r[fin], rtol=1e-11)
+    # a line of ONLY infinite values: mean inf, weighted std 0 (every term skipped), unweighted NaN
+    y = np.full((5, 3), np.inf)
+    y[:, 2] = 1.5
+    sy = np.full((5, 3), 0.1) if weighted else None
+    with np.errstate(all="ignore"):
+        ref = orc.dimension_statistics(y, sy, 0)
+    got = M(y, sy).compute_dimension_statistics(0)
+    for key in ("mean", "std"):
+        g, r = got[key].cpu().numpy(), np.asarray(ref[key])
+        assert np.array_equal(g, r, equal_nan=True), (key, g, r)
+    # the fused pair kernels: y = 0 makes the relative difference infinite
+    a = 0.2 + rng.random((64, 48, 3)); b = 0.3 + rng.random((64, 48, 3))
+    b[10, 10, 0] = 0.0; b[0, 0, 1] = 0.0; b[63, 47, 1] = 0.0          # +inf (channel 1: in the very first and the very last element)
+    a[5, 5, 2] = -0.3; b[5, 5, 2] = 0.0; b[6, 6, 2] = 0.0               # channel 2: -inf and +inf -> mean NaN
+    sa = 0.01 + 0.01 * rng.random(a.shape) if weighted else None
+    sb = 0.01 + 0.01 * rng.random(a.shape) if weighted else None
+    up = lambda v: None if v is None else torch.as_tensor(v, device="cuda")   # noqa: E731
+    with np.errstate(all="ignore"):
+        ad, ads, rd, rds = orc.compute_difference(a, sa, b, sb, 0.5)
+        refs = (orc.dimension_statistics(ad, ads, (0, 1)), orc.dimension_statistics(rd, rds, (0, 1)))
+    one = engine.pair_statistics(up(a), up(sa), up(b), up(sb), 0.5)
+    many = engine.pairs_statistics([up(a), up(b)], None if not weighted else [up(sa), up(sb)], [(0, 1, 0.5)])[0]
+    for got2 in (one, many):
+        for g_, r_ in zip(got2, refs):
+            for key in ("mean", "std"):
+                g, r = g_[key].cpu().numpy(), np.asarray(r_[key])
+                assert np.array_equal(np.isnan(g), np.isnan(r)) and np.array_equal(np.isinf(g), np.isinf(r)), (key, g, r)
+                fin = np.isfinite(r)
+                np.testing.assert_allclose(g[fin], r[fin], rtol=1e-9)
+                assert np.array_equal(g[~fin], r[~fin], equal_nan=True), (key, g, r)

@@ -289,3 +289,27 @@ def test_fuzz_tool_self_check():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 failures" in r.stdout
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_host_statistics_with_infinite_values(weighted):
+    """The host build on infinite values: NumPy's answers (mean +-inf / NaN by sign, nanstd NaN, the weighted formulas' inf or 0) - the same
+    cases the GPU suite runs through the HIP kernels (test_statistics_with_infinite_values_answer_like_numpy)."""
+    rng = np.random.default_rng(42)
+    shape = (17, 13, 4)
+    x = rng.normal(size=shape) + 3.0
+    x[rng.random(shape) < 0.1] = np.nan
+    x[3, 5, 0] = np.inf
+    x[7, 1, 1] = -np.inf
+    x[0, 0, 2] = np.inf; x[16, 12, 2] = -np.inf
+    s = 0.01 + 0.05 * rng.random(shape) if weighted else None
+    m = H(x.copy(), None if s is None else s.copy())
+    with np.errstate(all="ignore"):
+        for axis in ((0, 1), 0, None) + (() if weighted else (1, 2, (1, 2))):
+            ref = orc.dimension_statistics(x, s, axis)
+            got = m.compute_dimension_statistics(axis)
+            for key in ("mean", "std"):
+                g, r = np.asarray(got[key]), np.asarray(ref[key])
+                fin = np.isfinite(r)
+                assert np.array_equal(g[~fin], r[~fin], equal_nan=True), (axis, key, g, r)
+                np.testing.assert_allclose(g[fin], r[fin], rtol=1e-11)

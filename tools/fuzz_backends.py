@@ -26,6 +26,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--log", default=None)
+ap.add_argument("--one", default=None, help="<generator>:<seed> - re-run one reported case and print both sides of the first mismatch in full")
 ap.add_argument("--self-check", action="store_true", help="host build against itself (no GPU): exercises this script only")
 args = ap.parse_args()
 dev = torch.device("cpu" if args.self_check else "cuda:0")
@@ -75,6 +76,8 @@ def compare(what, a, b, rtol, atol=0.0):
         return 0.0
     if a.shape != b.shape:
         raise Mismatch(f"{what}: shapes {a.shape} vs {b.shape}")
+    if args.one:
+        say(f"  {what}: device {a.ravel()[:12]} host {b.ravel()[:12]}")
     if a.dtype.kind in "iub" or rtol is None:
         if not np.array_equal(a, b, equal_nan=a.dtype.kind == "f"):
             bad = np.flatnonzero(~((a == b) | ((a != a) & (b != b))).ravel()) if a.dtype.kind == "f" else np.flatnonzero((a != b).ravel())
@@ -369,11 +372,55 @@ def case_hist_extract(rng):
     return desc
 
 
+def case_linearity(rng):
+    """ExposureSeries.process_linearity's fused launch: in-place thresholds, every pair's absolute / relative difference statistics."""
+    c = int(rng.choice([1, 3, 3, 4]))
+    n = int(rng.integers(2, 8))
+    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+    if rng.random() < 0.3:
+        h, w = int(rng.integers(16, 64)), 64 * int(rng.integers(1, 5))
+    rad = rng.random((h, w, c)) * 4
+    t = np.sort(rng.uniform(0.01, 1.0, size=n))
+    vals = [np.clip(rad * ti + rng.normal(size=rad.shape) * 0.01, 0, None) for ti in t]
+    with_std = rng.random() < 0.5
+    stds = [0.004 * (1 + rng.random(rad.shape)) for _ in range(n)] if with_std else None
+    pairs = [(i, j, float(t[i] / t[j])) for i in range(n) for j in range(i + 1, n)]
+    if rng.random() < 0.5:
+        pairs = [pairs[int(q)] for q in rng.choice(len(pairs), size=int(rng.integers(1, len(pairs) + 1)), replace=False)]
+    thr = None
+    if rng.random() < 0.7:
+        thr = ([float(rng.uniform(0.0, 0.2)) for _ in range(c)], [float(rng.uniform(1.0, 4.0)) for _ in range(c)])
+    desc = f"linearity n={n} {h}x{w}x{c} pairs={len(pairs)} std={with_std} thresholds={thr is not None}"
+    va, vb = [D(v) for v in vals], [Hh(v) for v in vals]
+    sa = None if stds is None else [D(v) for v in stds]
+    sb = None if stds is None else [Hh(v) for v in stds]
+    ra = engine.pairs_statistics(va, sa, pairs, to_host=True, thresholds=thr)
+    rb = heng.pairs_statistics(vb, sb, pairs, to_host=True, thresholds=thr)
+    for q, ((aa, ar), (ba, br)) in enumerate(zip(ra, rb)):
+        for nm, x_, y_ in (("abs", aa, ba), ("rel", ar, br)):
+            for key in y_:
+                compare(f"pair{q}.{nm}.{key}", x_[key], y_[key], 1e-9 if key != "mean" else 1e-11, atol=1e-13 * 4)
+    if thr is not None:                                                # the thresholded frames (written in place) must agree exactly
+        for i in range(n):
+            compare(f"thresholded[{i}]", va[i], vb[i], None)
+            if stds is not None:
+                compare(f"thresholded_std[{i}]", sa[i], sb[i], None)
+    return desc
+
+
 CASES = [(case_merge, 5), (case_binary, 3), (case_unary, 1), (case_stats, 3), (case_pair, 2), (case_linearize, 2), (case_corrections, 2),
-         (case_hist_extract, 2)]
+         (case_hist_extract, 2), (case_linearity, 2)]
 weights = np.array([w for _, w in CASES], dtype=np.float64)
 weights /= weights.sum()
 counts = {fn.__name__: 0 for fn, _ in CASES}
+if args.one:
+    name, seed = args.one.split(":")
+    fn = dict((f.__name__, f) for f, _ in CASES)[name]
+    try:
+        say(fn(np.random.default_rng(int(seed))), "-> agree")
+    except Mismatch as e:
+        say("MISMATCH", e)
+    sys.exit(0)
 fails = 0
 t_end = time.time() + args.seconds
 t_say = time.time() + 10
