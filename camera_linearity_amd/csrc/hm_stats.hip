@@ -338,8 +338,8 @@ __device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s,
         w = 1.0;
     }
     a.K = (!a.haveK && use) ? v : a.K;
-    a.haveK = a.haveK || use;
-    const double we = use ? w : 0.0;
+    a.haveK = a.haveK || (use && w != 0.0);                                 // an element of weight 0 (std = inf) has added nothing yet: the next one
+    const double we = use ? w : 0.0;                                        // re-takes K (K far from the weighted data costs sqrt(eps) |K - mean| on the std)
     const double d = use ? v - a.K : 0.0;
     const double t = we * d;
     a.S0 += we; a.S1 += t; a.S2 = fma(t, d, a.S2);
@@ -393,8 +393,11 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
         if (use) {
             asm volatile("" ::: "memory");
             if constexpr (!LEAN) {
-                if (!a.haveK) { asm volatile("" ::: "memory"); a.K = finite_shift(v); }
-                a.haveK = true;
+                if (!a.haveK) {                       // (elements of weight 0 - std = inf - have added nothing: K is re-taken until one counts)
+                    asm volatile("" ::: "memory");
+                    a.K = finite_shift(v);
+                    a.haveK = WEIGHTED ? (w != 0.0) : true;
+                }
             }
             const double d = v - a.K;
             if constexpr (WEIGHTED) {
@@ -408,7 +411,7 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
     }
     if constexpr (!LEAN) {
         a.K = (!a.haveK && use) ? finite_shift(v) : a.K;
-        a.haveK = a.haveK || use;
+        a.haveK = a.haveK || (use && (!WEIGHTED || w != 0.0));
     }
     const double d = use ? v - a.K : 0.0;
     if constexpr (WEIGHTED) {
@@ -506,11 +509,12 @@ __device__ __forceinline__ void mom_finish(const Mom& m, bool weighted, double& 
         err = weighted ? m.ss / m.cs : nan;
         return;
     }
-    if (m.Wall == m.W) { mean = m.W == 0.0 ? nan : m.mean; sd = sqrt(m.M2 / m.Wall); }
+    const double M2 = fmax(m.M2, 0.0);                      // a sum of squares: rounding in S2 - S1^2 / S0 may leave -1e-13 where the data have no spread
+    if (m.Wall == m.W) { mean = m.W == 0.0 ? nan : m.mean; sd = sqrt(M2 / m.Wall); }
     else {                                                  // some weights belong to NaN values: the reference's denominators still count them
         mean = (m.W * m.mean) / m.Wall;
         const double d = m.mean - mean;
-        sd = sqrt((m.M2 + m.W * (d * d)) / m.Wall);
+        sd = sqrt((M2 + m.W * (d * d)) / m.Wall);
     }
     err = weighted ? m.ss / m.cs : nan;
 }

@@ -899,3 +899,26 @@ def test_statistics_with_infinite_values_answer_like_numpy(M, weighted):
                 fin = np.isfinite(r)
                 np.testing.assert_allclose(g[fin], r[fin], rtol=1e-9)
                 assert np.array_equal(g[~fin], r[~fin], equal_nan=True), (key, g, r)
+
+
+def test_statistics_zero_weight_first_element_and_no_spread(M):
+    """Two findings of tools/fuzz_backends.py with special values. A weighted line whose FIRST element has std = inf (weight 0) and whose
+    other element carries all the weight: the moments' shift must come from an element that counts (a shift 3 units from the weighted mean
+    gave std 3.5e-8 where NumPy has 0). And no spread at all must give 0, not sqrt(-1e-13) = NaN."""
+    x = np.array([[-80.964321, -84.078347], [-42.027734, -44.910037], [5.0, 5.0]])
+    s = np.array([[np.inf, 0.01097], [np.inf, 0.010663], [0.1, 0.1]])
+    got = M(x, s).compute_dimension_statistics(1)
+    with np.errstate(all="ignore"):
+        ref = orc.dimension_statistics(x, s, 1)
+    np.testing.assert_allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=1e-14)
+    np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=0, atol=1e-13)
+    # the same through the all-but-last-axes kernel and with many elements per lane
+    rng = np.random.default_rng(3)
+    big = np.full((4000, 3), 7.25); sb = np.full((4000, 3), np.inf)
+    big[:, 1] = rng.normal(size=4000); sb[:, 1] = 0.1
+    sb[1234, 0] = 0.5; sb[0, 2] = np.inf; sb[3999, 2] = 0.25; big[0, 2] = -1e6          # channel 2: a far outlier of weight 0 comes first
+    got = M(big, sb).compute_dimension_statistics(0)
+    with np.errstate(all="ignore"):
+        ref = orc.dimension_statistics(big, sb, 0)
+    np.testing.assert_allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=1e-12)
+    np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=1e-10, atol=1e-12)

@@ -27,6 +27,7 @@ ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--log", default=None)
 ap.add_argument("--one", default=None, help="<generator>:<seed> - re-run one reported case and print both sides of the first mismatch in full")
+ap.add_argument("--specials", type=float, default=0.3, help="share of cases whose float operands get NaN / +-inf / +-0 sprinkled in")
 ap.add_argument("--self-check", action="store_true", help="host build against itself (no GPU): exercises this script only")
 args = ap.parse_args()
 dev = torch.device("cpu" if args.self_check else "cuda:0")
@@ -104,6 +105,14 @@ def compare(what, a, b, rtol, atol=0.0):
 
 
 # ------------------------------------------------------------------------------------------------ case generators
+def sprinkle(rng, a, values=(np.nan, np.inf, -np.inf, 0.0, -0.0), p=0.03):
+    """special values into a float array (in place) for a third of the cases"""
+    if a is not None and args.specials > 0 and rng.random() < args.specials:
+        m = rng.random(a.shape) < p
+        a[m] = rng.choice(np.asarray(values, dtype=np.float64), size=int(m.sum()))
+    return a
+
+
 def icrf_tables(rng, c):
     g = np.linspace(0, 1, 256)[:, None] ** rng.uniform(0.6, 2.6, size=c)[None, :]
     if rng.random() < 0.2:
@@ -202,6 +211,7 @@ def case_binary(rng):
     y, ys = rand_operand(rng, sb, positive=(op == "div"))
     if op == "pow":
         y = rng.uniform(-2, 3, size=sb)
+    sprinkle(rng, x); sprinkle(rng, y); sprinkle(rng, xs, (np.nan, np.inf, 0.0)); sprinkle(rng, ys, (np.nan, np.inf, 0.0))
     desc = f"binary {op} {sa} {sb} std=({xs is not None},{ys is not None})"
     fn = {"add": lambda p, q: p + q, "sub": lambda p, q: p - q, "mul": lambda p, q: p * q, "div": lambda p, q: p / q, "pow": lambda p, q: p ** q}[op]
     ra = fn(Measurand(D(x), D(xs), use_cupy=GPU), Measurand(D(y), D(ys), use_cupy=GPU))
@@ -216,6 +226,7 @@ def case_unary(rng):
     shape = tuple(int(rng.integers(1, 40)) for _ in range(int(rng.integers(1, 4))))
     op = str(rng.choice(["neg", "log_e", "log_10"]))
     x, xs = rand_operand(rng, shape, positive=(op != "neg"))
+    sprinkle(rng, x, (np.nan, np.inf, -np.inf, 0.0, -0.0, -1.5)); sprinkle(rng, xs, (np.nan, np.inf, 0.0))
     fn = {"neg": lambda m: -m, "log_e": lambda m: m.log_e(), "log_10": lambda m: m.log_10()}[op]
     ra = fn(Measurand(D(x), D(xs), use_cupy=GPU))
     rb = fn(Measurand(x.copy(), None if xs is None else xs.copy(), use_cupy=False))
@@ -232,6 +243,7 @@ def case_stats(rng):
     x = rng.normal(size=shape) * 3 + rng.uniform(-100, 100)
     x[rng.random(shape) < rng.choice([0.0, 0.1, 0.6])] = np.nan
     xs = np.abs(rng.normal(size=shape)) * 0.1 + 0.01 if rng.random() < 0.5 else None
+    sprinkle(rng, x, (np.inf, -np.inf) if rng.random() < 0.5 else (np.inf,)); sprinkle(rng, xs, (np.nan, np.inf))
     r = rng.random()
     if r < 0.2:
         axis = None
@@ -247,6 +259,9 @@ def case_stats(rng):
             pass                                                       # the package defines every axis choice (keepdims mean), both builds must agree
     ra = Measurand(D(x), D(xs), use_cupy=GPU).compute_dimension_statistics(axis)
     rb = Measurand(x.copy(), None if xs is None else xs.copy(), use_cupy=False).compute_dimension_statistics(axis)
+    if args.one:                                                       # inputs and both answers, for a look on the host
+        np.savez("gpurun_out/fuzz_case_stats.npz", x=x, xs=np.zeros(0) if xs is None else xs, axis=np.asarray(-99 if axis is None else axis),
+                 **{f"dev_{k_}": as_np(v) for k_, v in ra.items() if v is not None}, **{f"host_{k_}": as_np(v) for k_, v in rb.items() if v is not None})
     assert ra.keys() == rb.keys(), (ra.keys(), rb.keys())
     mag = float(np.nanmax(np.abs(x))) if np.isfinite(x).any() else 0.0
     for key in rb:
@@ -265,6 +280,7 @@ def case_pair(rng):
         ys = None if xs is None else np.abs(rng.normal(size=sb)) * 0.05
         if xs is None:
             ys = None
+    sprinkle(rng, x, (np.nan, np.inf, 0.0)); sprinkle(rng, y, (np.nan, np.inf, 0.0)); sprinkle(rng, xs, (np.nan, 0.0)); sprinkle(rng, ys, (np.nan, 0.0))
     mult = float(rng.uniform(0.1, 8))
     lo = [float(rng.uniform(0, 0.5)) if rng.random() < 0.7 else None for _ in range(c)]
     hi = [float(rng.uniform(5, 50)) if rng.random() < 0.7 else None for _ in range(c)]
