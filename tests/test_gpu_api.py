@@ -907,9 +907,10 @@ def test_statistics_zero_weight_first_element_and_no_spread(M):
     gave std 3.5e-8 where NumPy has 0). And no spread at all must give 0, not sqrt(-1e-13) = NaN."""
     x = np.array([[-80.964321, -84.078347], [-42.027734, -44.910037], [5.0, 5.0]])
     s = np.array([[np.inf, 0.01097], [np.inf, 0.010663], [0.1, 0.1]])
-    got = M(x, s).compute_dimension_statistics(1)
+    x, s = np.ascontiguousarray(x.T), np.ascontiguousarray(s.T)          # lines along axis 0 (the reference's weighted formula broadcasts only there)
+    got = M(x, s).compute_dimension_statistics(0)
     with np.errstate(all="ignore"):
-        ref = orc.dimension_statistics(x, s, 1)
+        ref = orc.dimension_statistics(x, s, 0)
     np.testing.assert_allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=1e-14)
     np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=0, atol=1e-13)
     # the same through the all-but-last-axes kernel and with many elements per lane
