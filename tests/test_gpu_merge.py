@@ -1408,3 +1408,44 @@ def test_plan_graph_replays_every_launch_bit_identically(eng):
                 f.copy_(torch.flip(f, dims=(1,)))
     with pytest.raises(ValueError):
         eng.PlanGraph([])
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4tile"])
+def test_full_size_device_output_equals_the_host_build(eng, cfg):
+    """BASELINE.json's configurations AT FULL SIZE, every output element compared: the HIP kernels' result against the independent plain-C++
+    build of the same ABI (libhdrmerge_host.so; itself pinned to the reference-generated goldens and the oracle in the CPU suite) -
+    bit for bit. cfg2: 7 x 4096 x 4096 x 3 val-only (merge_u8_val3); cfg3: the same stack with float64 std frames, seven DISTINCT dark maps
+    (k = 3 medians) and a flat field (merge_u8_fast_std + scan + patch); cfg4tile: rows 3072..4095 of a 15 x 8192 x 8192 x 3 image with
+    the tile's halo rows. 50-100 million elements each; the host build takes a few seconds on the box's cores."""
+    from camera_linearity_amd.measurand import _HOST_ENGINE as heng
+    from camera_linearity_amd.synthetic import synthetic_stack_device, synthetic_icrf, synthetic_flat_dark
+    icrf, diff = synthetic_icrf()
+    cpu = lambda t: None if t is None else t.cpu()   # noqa: E731
+    if cfg == "cfg4tile":
+        n, H, W = 15, 1026, 8192                        # buffer rows 3071..4096 of the image: one halo row above and below the tile
+        frames, _, t = synthetic_stack_device(11, n, H, W)
+        kw = dict(height=8192, row0=3072, rows=1024, buf_row0=3071)
+        d_out = eng.merge(frames, t, icrf, **kw)
+        h_out = heng.merge([cpu(f) for f in frames], t, icrf, **kw)
+    else:
+        n, H, W = 7, 4096, 4096
+        with_std = cfg == "cfg3"
+        frames, stds, t = synthetic_stack_device(7, n, H, W, with_std=with_std)
+        kw_d, kw_h = {}, {}
+        if with_std:
+            flat, flat_std, _ = synthetic_flat_dark(7, H, W)
+            darks = [synthetic_flat_dark(20 + i, H, W, hot_density=1e-4)[2] for i in range(n)]
+            x0, x1, y0, y1 = eng.flat_roi_bounds(H, W, 0.5)
+            m = eng.roi_mean(flat, x0, x1, y0, y1).cpu().numpy()
+            sm = eng.roi_mean(flat_std, x0, x1, y0, y1).cpu().numpy()
+            common = dict(dark_min=[100] * n, median_k=3, ff_mean=m, ff_std_mean=sm)
+            kw_d = dict(darks=darks, flat=flat, flat_std=flat_std, **common)
+            kw_h = dict(darks=[cpu(d) for d in darks], flat=cpu(flat), flat_std=cpu(flat_std), **common)
+        d_out = eng.merge(frames, t, icrf, diff if with_std else None, stds, **kw_d)
+        h_out = heng.merge([cpu(f) for f in frames], t, icrf, diff if with_std else None, None if stds is None else [cpu(s) for s in stds], **kw_h)
+    assert set(d_out) == set(h_out)
+    for key in h_out:
+        got = d_out[key].cpu()
+        assert got.shape == h_out[key].shape and got.shape[0] == (1024 if cfg == "cfg4tile" else 4096)
+        assert torch.equal(got, h_out[key]), (cfg, key, int((got != h_out[key]).sum()))
+        assert bool(torch.isfinite(got).all())
