@@ -8,7 +8,7 @@
 //
 // Arithmetic: the operation sequence of the device kernels, element by element (merge_one_element of hm_merge.hip, the operator
 // formulas of hm_ops.hip, ...), each citing the reference line it follows. Statistics use the reference's own two-pass form.
-// Not here: the upstream producers (hm_welford_*, hm_linearity_energy - device-only rows of SURVEY.md 8f-2/3: HM_EUNSUPPORTED),
+// Since round 4 also the upstream producers (hm_welford_*, hm_linearity_energy: SURVEY.md 8f-2/3). Not here:
 // the TIFF strip decoders (host code already, in libhdrmerge.so) and the hm_debug_* probes.
 #include "hdrmerge.h"
 
@@ -733,12 +733,121 @@ int hm_channel_histogram(const double* val, const double* std_, int64_t n, int C
     return HM_OK;
 }
 
-// ---- device-only rows -----------------------------------------------------------------------------------------------
-int hm_welford_update(const void* const*, int, int64_t, const double*, double*, double*, int64_t, int, void*) { return HM_EUNSUPPORTED; }
-int hm_welford_finalize(const double*, const double*, int64_t, uint8_t*, uint8_t*, int64_t, void*) { return HM_EUNSUPPORTED; }
+// ---- the producers ---------------------------------------------------------------------------------
+// welford_algorithm, modules/video_processing.py:161-219: per element, frames in order - delta = f - mean; mean += delta / n;
+// m2 += delta * (f - mean) (:205-208), f = icrf[dn, c] (:200-201) or dn / 255 (:203)
+int hm_welford_update(const void* const* frames, int n_frames, int64_t count_before, const double* icrf, double* mean, double* m2,
+                      int64_t n_elems, int C, void*) {
+    if (n_frames < 0 || n_frames > HM_MAX_FRAMES || count_before < 0 || n_elems < 0) return HM_EINVAL;
+    if (count_before > (int64_t{1} << 40)) return HM_EUNSUPPORTED;              // (the device build's limit: one ABI, one answer)
+    if (C < 1 || C > HM_MAX_CHANNELS) return HM_ESHAPE;
+    if (n_elems % C != 0) return HM_ESHAPE;
+    if (n_frames == 0 || n_elems == 0) return HM_OK;
+    if (!frames || !mean) return HM_EINVAL;
+    for (int k = 0; k < n_frames; ++k) if (!frames[k]) return HM_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n_elems; ++e) {
+        const int c = static_cast<int>(e % C);
+        double m = mean[e], q = m2 ? m2[e] : 0.0, cnt = static_cast<double>(count_before);
+        for (int k = 0; k < n_frames; ++k) {
+            cnt += 1.0;
+            const int dn = static_cast<const uint8_t*>(frames[k])[e];
+            const double f = icrf ? icrf[dn * C + c] : static_cast<double>(dn) / 255.0;
+            const double delta = f - m;
+            m = m + delta / cnt;
+            q = q + delta * (f - m);
+        }
+        mean[e] = m;
+        if (m2) m2[e] = q;
+    }
+    return HM_OK;
+}
+
+// np.around(x).astype(uint8) as the device build defines it: round half even, NaN and |x| >= 2^63 -> 0, else the low byte
+static inline uint8_t round_to_u8(double x) {
+    const double r = std::nearbyint(x);
+    if (!(r == r) || r >= 9.2e18 || r <= -9.2e18) return 0;
+    return static_cast<uint8_t>(static_cast<uint64_t>(static_cast<int64_t>(r)) & 255u);
+}
+
+int hm_welford_finalize(const double* mean, const double* m2, int64_t count, uint8_t* out_mean, uint8_t* out_std, int64_t n_elems, void*) {
+    if (n_elems < 0 || count < 1) return HM_EINVAL;
+    if (n_elems == 0) return HM_OK;
+    if ((out_mean && !mean) || (out_std && !m2)) return HM_EINVAL;
+    if (out_std && count < 2) return HM_EINVAL;                                   // m2 / (n - 1) needs two frames (:214)
+    const double denom = static_cast<double>(count) - 1.0, root_n = std::sqrt(static_cast<double>(count));
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n_elems; ++e) {
+        if (out_mean) out_mean[e] = round_to_u8(mean[e] * 255.0);                 // :210-211
+        if (out_std) out_std[e] = round_to_u8(std::sqrt(m2[e] / denom) / root_n); // :214-215, as written
+    }
+    return HM_OK;
+}
 int64_t hm_welford_algorithmic_bytes(int n_frames, int with_m2, int64_t n_elems) { return n_elems * (static_cast<int64_t>(n_frames) + (with_m2 ? 32 : 16)); }
+
+// _energy_function + analyze_linearity, modules/ICRF_calibration_exposure.py:66-145,148-201, for n_candidates ICRFs of one channel:
+// per candidate and exposure pair (i < j, np.triu_indices order) the (weighted) mean of |v_i - v_j t_i/t_j| (/ (v_j t_i/t_j) when
+// relative) over the pixels whose values lie inside [icrf[lower], icrf[upper]]; the energy is the nanmean over the pairs, +inf for NaN
 size_t hm_linearity_energy_workspace_bytes(int64_t, int, int) { return 0; }
-int hm_linearity_energy(const uint8_t*, const double*, const double*, const double*, const uint8_t*, int, int, int, int, int64_t, int,
-                        double*, double*, void*, void*) { return HM_EUNSUPPORTED; }
+int hm_linearity_energy(const uint8_t* dn, const double* std_, const double* exposures, const double* icrf, const uint8_t* valid,
+                        int n_candidates, int lower, int upper, int use_relative, int64_t n_pixels, int n_frames,
+                        double* out_pairs, double* out_energy, void*, void*) {
+    if (n_candidates < 0 || n_pixels < 0) return HM_EINVAL;
+    if (n_frames < 2 || n_frames > HM_MAX_FRAMES) return HM_ESHAPE;
+    if (lower < 0 || lower > 255 || upper < 0 || upper > 255) return HM_EINVAL;
+    if (n_candidates == 0) return HM_OK;
+    if (n_candidates > 65535) return HM_EUNSUPPORTED;
+    if (!dn || !exposures || !icrf || !out_energy) return HM_EINVAL;
+    const int N = n_frames, pairs = N * (N - 1) / 2;
+    std::vector<int> pi(pairs), pj(pairs);
+    { int p = 0; for (int i = 0; i < N; ++i) for (int j = i + 1; j < N; ++j, ++p) { pi[p] = i; pj[p] = j; } }
+    std::vector<double> res(static_cast<size_t>(n_candidates) * pairs);
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int b = 0; b < n_candidates; ++b)
+        for (int p = 0; p < pairs; ++p) {
+            double& r = res[static_cast<size_t>(b) * pairs + p];
+            if (valid && !valid[b]) { r = kNaN; continue; }
+            const double* lut = icrf + static_cast<int64_t>(b) * 256;
+            const double lo = lut[lower], hi = lut[upper];
+            const int i = pi[p], j = pj[p];
+            const double ratio = exposures[i] / exposures[j];                            // :100
+            double num = 0.0, den = 0.0;
+            for (int64_t px = 0; px < n_pixels; ++px) {
+                double vi = lut[dn[px * N + i]], vj = lut[dn[px * N + j]];
+                if (vi < lo || vi > hi) vi = kNaN;                                       // :96-97
+                if (vj < lo || vj > hi) vj = kNaN;
+                const double scaled = vj * ratio;                                        // :111
+                double d = vi - scaled;                                                  // :114
+                if (use_relative) d = d / scaled;                                        // :117
+                const double ad = std::fabs(d);                                          // :120
+                if (std_) {
+                    const double si = std_[px * N + i], sj = std_[px * N + j];
+                    double sigma;
+                    if (use_relative) {
+                        const double u = si / scaled, v = (vi * sj) / (ratio * (vj * vj));   // :127
+                        sigma = std::sqrt(u * u + v * v);
+                    } else {
+                        const double v = ratio * sj;
+                        sigma = std::sqrt(si * si + v * v);                              // :129
+                    }
+                    const double w = 1.0 / sigma;
+                    if (std::isfinite(ad) && sigma != 0.0 && w == w) { num += ad * w; den += w; }   // :133-134, general_functions.py:164-174
+                } else if (ad == ad) { num += ad; den += 1.0; }                          // :138
+            }
+            r = num / den;                                                               // 0 / 0 = NaN: no contributing pixel
+        }
+    for (int b = 0; b < n_candidates; ++b) {
+        const bool ok = !valid || valid[b];
+        double sum = 0.0, cnt = 0.0;
+        for (int p = 0; p < pairs; ++p) {
+            const double r = res[static_cast<size_t>(b) * pairs + p];
+            if (out_pairs) out_pairs[static_cast<int64_t>(b) * pairs + p] = r;
+            if (r == r) { sum += r; cnt += 1.0; }
+        }
+        const double e = sum / cnt;                                                      // :196
+        out_energy[b] = (ok && e == e) ? e : std::numeric_limits<double>::infinity();    // :197-200
+    }
+    return HM_OK;
+}
 
 }  // extern "C"

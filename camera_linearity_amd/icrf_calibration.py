@@ -53,13 +53,22 @@ def analyze_linearity(image_value_stack: torch.Tensor, image_std_stack: Optional
                       use_relative: bool, exposure_values):
     """:66-145 for a uint8 DN stack seen through one ICRF: the N(N-1)/2 pair results (device tensor) in
     np.triu_indices(N, 1) order. `lower` / `upper` are DN limits (the energy function maps them through the ICRF, :181-182)."""
-    _, pairs = engine.linearity_energy(image_value_stack, image_std_stack, _host(exposure_values), np.asarray(ICRF_ch)[None],
-                                       lower, upper, None, use_relative, return_pairs=True)
+    _, pairs = _engine_for(image_value_stack).linearity_energy(image_value_stack, image_std_stack, _host(exposure_values),
+                                                               np.asarray(ICRF_ch)[None], lower, upper, None, use_relative, return_pairs=True)
     return pairs[0]
 
 
 def _host(x):
     return x.cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
+
+
+def _engine_for(stack: torch.Tensor):
+    """The HIP library for a device-resident stack; the host build of the same ABI for a host stack (initialize_channel_image_stacks(...,
+    device="cpu")) - the caller's explicit choice, never a fallback."""
+    if not isinstance(stack, torch.Tensor) or stack.is_cuda:        # (anything but a tensor: engine raises the TypeError)
+        return engine
+    from .measurand import _HOST_ENGINE
+    return _HOST_ENGINE
 
 
 def energy_function_batch(PCA_params, mean_ICRF, PCA_array, image_value_stack, image_std_stack, lower, upper, use_mean,
@@ -68,7 +77,7 @@ def energy_function_batch(PCA_params, mean_ICRF, PCA_array, image_value_stack, i
     icrfs, valid = candidate_icrfs(PCA_params, mean_ICRF, PCA_array, use_mean)
     if not valid.any():
         return np.full(len(valid), np.inf)
-    e = engine.linearity_energy(image_value_stack, image_std_stack, _host(exposure_values), icrfs, int(lower), int(upper),
+    e = _engine_for(image_value_stack).linearity_energy(image_value_stack, image_std_stack, _host(exposure_values), icrfs, int(lower), int(upper),
                                 valid, True)
     return e.cpu().numpy()
 

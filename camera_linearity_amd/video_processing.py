@@ -20,6 +20,16 @@ import torch
 
 from . import engine
 
+
+def _engine_for(device: torch.device):
+    """The HIP library for a GPU device; the host build of the same ABI for device="cpu" - an explicit choice (the reference's NumPy
+    slot), never a fallback: the default device is the current GPU and the calls below raise without one."""
+    if device.type == "cuda":
+        return engine
+    from .measurand import _HOST_ENGINE
+    return _HOST_ENGINE
+
+
 FRAMES_PER_LAUNCH = 32      # = HM_MAX_FRAMES: state traffic per element-frame = 32 / 32 = 1 byte with std (measured best)
 
 
@@ -47,6 +57,8 @@ def _as_device_frame(frame, device) -> torch.Tensor:
         raise TypeError(f"video frames must be uint8, got {t.dtype}")
     if t.dim() == 2:
         t = t[..., None]
+    if torch.device(device).type == "cpu":
+        return t.clone()                      # (a capture may hand out the same buffer again; a batch of frames is pending at a time)
     return t.to(device, non_blocking=True)
 
 
@@ -60,10 +72,12 @@ def welford_algorithm(frame_sources: Union[Iterable, Sequence[Iterable]], ICRF: 
             into one result). A frame of None ends a source (the reference's generator protocol, :192-193).
         ICRF: (BITS, NUM_OF_CHS) float64 inverse camera response; frames are linearized on load when given.
         use_std: whether to compute the standard deviation frame.
+        device: the GPU to compute on (default: the current one), or "cpu" for the host build (libhdrmerge_host.so).
     Returns:
         {'mean': uint8 (H, W, C), 'std': uint8 (H, W, C) or None} - NumPy arrays (or device tensors with as_numpy=False).
     """
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    eng = _engine_for(device)
     if frames_per_launch < 1:
         raise ValueError("frames_per_launch must be positive")
     if isinstance(frame_sources, (list, tuple)) and frame_sources and not _looks_like_frame(frame_sources[0]):
@@ -78,7 +92,7 @@ def welford_algorithm(frame_sources: Union[Iterable, Sequence[Iterable]], ICRF: 
     def flush():
         nonlocal count
         if pending:
-            count = engine.welford_update(pending, count, mean, m2, ICRF)
+            count = eng.welford_update(pending, count, mean, m2, ICRF)
             pending.clear()
 
     for source in sources:
@@ -99,7 +113,7 @@ def welford_algorithm(frame_sources: Union[Iterable, Sequence[Iterable]], ICRF: 
         raise ValueError("no frames to process")
     if use_std and count < 2:
         raise ValueError("the standard deviation frame needs at least two frames")
-    out_mean, out_std = engine.welford_finalize(mean, m2, count)
+    out_mean, out_std = eng.welford_finalize(mean, m2, count)
     if as_numpy:
         return {"mean": out_mean.cpu().numpy(), "std": None if out_std is None else out_std.cpu().numpy()}
     return {"mean": out_mean, "std": out_std}

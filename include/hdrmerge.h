@@ -25,7 +25,7 @@
  * Two libraries export this ABI. libhdrmerge.so (the .hip files under csrc/) is the MI355X build described above. libhdrmerge_host.so
  * (csrc_host/hm_host.cpp, plain C++) is the HOST build behind Measurand(use_cupy=False) - the slot of the reference's NumpyMeasurand
  * (modules/measurand_factory.py:10-14): every pointer is then a HOST pointer, `stream` is ignored, calls are synchronous and workspaces
- * may be NULL; hm_welford_* and hm_linearity_energy are device-only there (HM_EUNSUPPORTED), the hm_tiff_* decoders are not exported.
+ * may be NULL; the hm_tiff_* decoders are not exported (they are host code of libhdrmerge.so already).
  * The device build never calls or falls back to the host build.
  */
 #ifndef HDRMERGE_H

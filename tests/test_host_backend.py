@@ -243,9 +243,6 @@ def test_host_backend_is_explicit_and_isolated():
     s = ImageSet(value=np.zeros((2, 2, 3)))
     with pytest.raises(ValueError, match="Expected type numpy"):
         s.measurand = HipMeasurand(None, None)
-    with pytest.raises(NotImplementedError):                             # device-only rows stay device-only
-        with nat.host_mode():
-            engine.welford_update([f], 0, torch.zeros((4, 4, 3), dtype=torch.float64), None)
 
 
 def test_host_library_exports_the_abi():
@@ -313,3 +310,47 @@ def test_host_statistics_with_infinite_values(weighted):
                 fin = np.isfinite(r)
                 assert np.array_equal(g[~fin], r[~fin], equal_nan=True), (axis, key, g, r)
                 np.testing.assert_allclose(g[fin], r[fin], rtol=1e-11)
+
+
+@pytest.mark.parametrize("use_icrf", [False, True])
+def test_host_welford_matches_oracle(use_icrf):
+    """video_processing.welford_algorithm(..., device="cpu"): the host build's hm_welford_update / hm_welford_finalize against the oracle's
+    restatement of modules/video_processing.py:161-219 - 45 frames (two launches of 32 + 13), mean and std frames exact (uint8)."""
+    from camera_linearity_amd import video_processing as vp
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (20, 30, 3)).astype(np.uint8) for _ in range(45)]
+    icrf, _ = orc.synthetic_icrf()
+    got = vp.welford_algorithm(iter(frames), icrf if use_icrf else None, use_std=True, device="cpu")
+    ref = orc.welford(frames, icrf if use_icrf else None, True)
+    assert np.array_equal(got["mean"], ref["mean"]) and np.array_equal(got["std"], ref["std"])
+    only_mean = vp.welford_algorithm([iter(frames[:20]), iter(frames[20:])], None, use_std=False, device="cpu")
+    assert only_mean["std"] is None and np.array_equal(only_mean["mean"], orc.welford(frames, None, False)["mean"])
+    with pytest.raises(ValueError):
+        vp.welford_algorithm(iter(frames[:1]), None, use_std=True, device="cpu")
+
+
+@pytest.mark.parametrize("use_std", [False, True])
+def test_host_energy_function_matches_oracle(use_std):
+    """icrf_calibration on a host stack (initialize_channel_image_stacks(..., device="cpu")): the host build's hm_linearity_energy against
+    the oracle's _energy_function / analyze_linearity (modules/ICRF_calibration_exposure.py:66-201): valid candidates to 1e-12, a
+    non-monotonic and an out-of-range candidate +inf, per-pair results incl. NaN pairs."""
+    from camera_linearity_amd import icrf_calibration as ic
+    rng = np.random.default_rng(1)
+    X, Y, N = 24, 18, 5
+    dn = np.sort(rng.integers(0, 256, (X, Y, N)).astype(np.uint8), axis=2)
+    sd = 0.004 * (1 + rng.random((X, Y, N))) if use_std else None
+    t = 1e-3 * 2.0 ** np.arange(N)
+    cands = np.stack([np.linspace(0, 1, 256) ** g for g in (0.8, 1.0, 2.2, 1.7)])
+    bad = cands[1].copy(); bad[100] = bad[99]                        # not strictly increasing
+    cands = np.vstack([cands, bad[None]])
+    valid = np.array([orc.candidate_valid(c) for c in cands])
+    assert list(valid) == [True, True, True, True, False]
+    vt, st = torch.from_numpy(dn), None if sd is None else torch.from_numpy(sd)
+    e, pairs = ic._engine_for(vt).linearity_energy(vt, st, t, cands, 5, 250, valid, True, return_pairs=True)
+    ref = np.array([orc.energy_function(c, dn, sd, 5, 250, t) for c in cands])
+    assert np.isinf(e.numpy()[4]) and np.isinf(ref[4])
+    np.testing.assert_allclose(e.numpy()[:4], ref[:4], rtol=1e-12)
+    ref_pairs = orc.analyze_linearity_pairs(cands[2][dn], sd, cands[2][5], cands[2][250], True, t)
+    np.testing.assert_allclose(pairs.numpy()[2], ref_pairs, rtol=1e-12, equal_nan=True)
+    one = ic.analyze_linearity(vt, st, cands[2], 5, 250, True, t)
+    np.testing.assert_allclose(one.numpy(), ref_pairs, rtol=1e-12, equal_nan=True)

@@ -424,8 +424,59 @@ def case_linearity(rng):
     return desc
 
 
+def case_welford(rng):
+    """hm_welford_update / hm_welford_finalize: mean / M2 state after several launches and the uint8 result frames - bit-exact (the device's
+    division by the frame count is proven equal to the IEEE quotient in its accepted range and falls back to it outside)."""
+    c = int(rng.choice([1, 3, 3, 4]))
+    h, w = int(rng.integers(1, 30)), int(rng.integers(1, 40))
+    n = int(rng.integers(1, 80))
+    use_m2 = rng.random() < 0.7
+    use_icrf = rng.random() < 0.5
+    g = icrf_tables(rng, c)[0] if use_icrf else None
+    lo = int(rng.integers(0, 200)); hi = int(rng.integers(lo + 1, 257))
+    frames = [rng.integers(lo, hi, (h, w, c)).astype(np.uint8) for _ in range(n)]
+    splits = sorted(set(int(q) for q in rng.integers(1, n + 1, size=int(rng.integers(0, 3))))) + [n]
+    desc = f"welford n={n} {h}x{w}x{c} m2={use_m2} icrf={use_icrf} launches at {splits}"
+    out = []
+    for eng_, conv, dv in ((engine, D, dev), (heng, Hh, torch.device("cpu"))):
+        mean = torch.zeros((h, w, c), dtype=torch.float64, device=dv)
+        m2 = torch.zeros((h, w, c), dtype=torch.float64, device=dv) if use_m2 else None
+        count, k0 = 0, 0
+        for k1 in splits:
+            count = eng_.welford_update([conv(f) for f in frames[k0:k1]], count, mean, m2, g)
+            k0 = k1
+        fm, fs = eng_.welford_finalize(mean, m2 if count >= 2 else None, count)
+        out.append((mean, m2, fm, fs))
+    for nm, a, b in zip(("mean", "m2", "mean_u8", "std_u8"), *out):
+        compare(nm, a, b, None)
+    return desc
+
+
+def case_energy(rng):
+    """hm_linearity_energy: a population of candidate ICRFs (some rejected) on one channel's (X, Y, N) stack; energies and per-pair results
+    to 1e-11 (the device's register kernel multiplies by reciprocals; sums run in another order), NaN / inf patterns equal."""
+    X, Y = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    N = int(rng.choice([2, 3, 5, 7, 8, 9, 12]))
+    B = int(rng.choice([1, 3, 8, 20]))
+    dn = np.sort(rng.integers(0, 256, (X, Y, N)).astype(np.uint8), axis=2)
+    sd = 0.004 * (1 + rng.random((X, Y, N))) if rng.random() < 0.5 else None
+    if sd is not None and rng.random() < 0.3:
+        sd[rng.random(sd.shape) < 0.05] = 0.0
+    t = np.sort(rng.uniform(1e-3, 1.0, size=N)) + np.arange(N) * 1e-4
+    cands = np.linspace(0, 1, 256)[None, :] ** rng.uniform(0.5, 2.5, size=B)[:, None]
+    valid = rng.random(B) < 0.8
+    lower, upper = int(rng.integers(0, 40)), int(rng.integers(200, 256))
+    rel = bool(rng.random() < 0.7)
+    desc = f"energy {X}x{Y}x{N} B={B} std={sd is not None} rel={rel} limits=({lower},{upper})"
+    ea, pa = engine.linearity_energy(D(dn), D(sd), t, cands, lower, upper, valid, rel, return_pairs=True)
+    eb, pb = heng.linearity_energy(Hh(dn), Hh(sd), t, cands, lower, upper, valid, rel, return_pairs=True)
+    compare("energy", ea, eb, 1e-11)
+    compare("pairs", pa, pb, 1e-11)
+    return desc
+
+
 CASES = [(case_merge, 5), (case_binary, 3), (case_unary, 1), (case_stats, 3), (case_pair, 2), (case_linearize, 2), (case_corrections, 2),
-         (case_hist_extract, 2), (case_linearity, 2)]
+         (case_hist_extract, 2), (case_linearity, 2), (case_welford, 2), (case_energy, 2)]
 weights = np.array([w for _, w in CASES], dtype=np.float64)
 weights /= weights.sum()
 counts = {fn.__name__: 0 for fn, _ in CASES}
