@@ -423,6 +423,16 @@ def producer_workload(a, dev, rank=0, world=1, dist=None):
             cpu = {"value": round(rows_c * W * K / dt / 1e6, 3), "unit": unit, "cores": 1, "kind": "port",
                    "sample": f"{K} frames of {rows_c}x{W}x3 ({dt:.1f} s), NumPy oracle, 1 thread; the same band folded once on the GPU is compared with it",
                    "gpu_vs_oracle_max_rel_err": e_mean, "gpu_vs_oracle_max_rel_err_m2": e_m2, "parity_ok": bool(e_mean <= 1e-13 and e_m2 <= 1e-12)}
+            # the package's own host build of the same entry point (libhdrmerge_host.so, OpenMP) on the same band: bit-identical to the device
+            from camera_linearity_amd.measurand import _HOST_ENGINE as heng
+            hm_, h2_ = torch.zeros((rows_c, W, 3), dtype=torch.float64), torch.zeros((rows_c, W, 3), dtype=torch.float64)
+            hs = [torch.from_numpy(x) for x in sample]
+            c0 = time.perf_counter()
+            heng.welford_update(hs, 0, hm_, h2_)
+            dt_h = time.perf_counter() - c0
+            cpu["host_backend"] = {"value": round(rows_c * W * K / dt_h / 1e6, 3), "unit": unit, "cores": min(16, os.cpu_count() or 1),
+                                   "kind": "product host build (libhdrmerge_host.so, OpenMP)",
+                                   "bit_identical_to_gpu": bool(torch.equal(hm_, gm.cpu()) and torch.equal(h2_, g2.cpu()))}
         else:
             reps = 10
             c0 = time.perf_counter()
@@ -433,6 +443,13 @@ def producer_workload(a, dev, rank=0, world=1, dist=None):
             cpu = {"value": round(reps / dt, 4), "unit": unit, "cores": 1, "kind": "port",
                    "sample": f"{reps} of the 75 candidates on the full 1024x1024x7 stack ({dt:.1f} s), NumPy oracle, 1 thread; the GPU energies of the same candidates are compared with it",
                    "gpu_vs_oracle_max_rel_err": worst, "parity_ok": bool(worst <= 1e-10)}
+            from camera_linearity_amd.measurand import _HOST_ENGINE as heng
+            c0 = time.perf_counter()
+            got_h = heng.linearity_energy(torch.from_numpy(dn_h), None, t, icrfs[:reps], 5, 250).numpy()
+            dt_h = time.perf_counter() - c0
+            cpu["host_backend"] = {"value": round(reps / dt_h, 3), "unit": unit, "cores": min(16, os.cpu_count() or 1),
+                                   "kind": "product host build (libhdrmerge_host.so, OpenMP)",
+                                   "max_rel_diff_to_gpu": float(np.max(np.abs(got_h - got) / np.abs(got)))}
     scale_u = 1e6 if unit.startswith("M") else 1.0
     traffic, traffic_src, traffic_stale = measured_traffic(a.workload)
     line = {"metric": metric, "value": round(world * steps * units / elapsed / scale_u, 2), "unit": unit, "n_gpus": world, "steps": steps, "warmup": warmup,

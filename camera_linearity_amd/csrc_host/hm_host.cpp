@@ -811,8 +811,9 @@ int hm_linearity_energy(const uint8_t* dn, const double* std_, const double* exp
             const double lo = lut[lower], hi = lut[upper];
             const int i = pi[p], j = pj[p];
             const double ratio = exposures[i] / exposures[j];                            // :100
-            double num = 0.0, den = 0.0;
-            for (int64_t px = 0; px < n_pixels; ++px) {
+            double num = 0.0, den = 0.0, bnum = 0.0, bden = 0.0;                       // sums in blocks of 1024 pixels (a million-term running sum
+            for (int64_t px = 0; px < n_pixels; ++px) {                                  // loses three more digits than NumPy's pairwise one)
+                if ((px & 1023) == 0) { num += bnum; den += bden; bnum = 0.0; bden = 0.0; }
                 double vi = lut[dn[px * N + i]], vj = lut[dn[px * N + j]];
                 if (vi < lo || vi > hi) vi = kNaN;                                       // :96-97
                 if (vj < lo || vj > hi) vj = kNaN;
@@ -831,9 +832,10 @@ int hm_linearity_energy(const uint8_t* dn, const double* std_, const double* exp
                         sigma = std::sqrt(si * si + v * v);                              // :129
                     }
                     const double w = 1.0 / sigma;
-                    if (std::isfinite(ad) && sigma != 0.0 && w == w) { num += ad * w; den += w; }   // :133-134, general_functions.py:164-174
-                } else if (ad == ad) { num += ad; den += 1.0; }                          // :138
+                    if (std::isfinite(ad) && sigma != 0.0 && w == w) { bnum += ad * w; bden += w; }   // :133-134, general_functions.py:164-174
+                } else if (ad == ad) { bnum += ad; bden += 1.0; }                        // :138
             }
+            num += bnum; den += bden;
             r = num / den;                                                               // 0 / 0 = NaN: no contributing pixel
         }
     for (int b = 0; b < n_candidates; ++b) {
