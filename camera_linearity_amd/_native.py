@@ -102,6 +102,8 @@ _SIGNATURES = {
     "hm_channel_statistics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hm_axis_statistics_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
     "hm_axis_statistics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hm_axis_statistics2_workspace_bytes": (C.c_size_t, [C.c_int64] * 5),
+    "hm_axis_statistics2": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p] * 5),
     "hm_compute_difference_bcast": (C.c_int, [C.c_void_p] * 4 + [C.c_double] + [C.c_void_p] * 4 + [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                                                               C.POINTER(C.c_int64), C.c_void_p]),
     "hm_interpolate_bcast": (C.c_int, [C.c_void_p] * 4 + [C.c_double] * 3 + [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),

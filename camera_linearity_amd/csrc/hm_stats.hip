@@ -1395,8 +1395,8 @@ extern "C" int hm_channel_histogram(const double* val, const double* std, int64_
 
 // ================================================================================================
 // compute_dimension_statistics over ANY axis (modules/measurand.py:318-350 take a NumPy axis argument): the array is seen as a dense
-// (outer, A, inner) block and reduced over A - out[o, i] from x[(o A + k) inner + i], k = 0..A-1. (Reduced axes that are not adjacent
-// are brought together by the caller with a layout copy.) Same one-pass moments and NaN rules as the channel statistics above
+// (outer, A, inner) block and reduced over A - out[o, i] from x[(o A + k) inner + i], k = 0..A-1. (Two separate groups of reduced axes:
+// hm_axis_statistics2 / k_axis_final2 below; three or more are brought together by the caller with a layout copy.) Same one-pass moments and NaN rules as the channel statistics above
 // (MomAcc / mom_merge / mom_finish). Two shapes:
 //   k_axis_thread   one thread per output (o, i): lanes run along i (contiguous) - inner >= 16, or short axes (A <= 32: e.g. the
 //                   channel axis of an image, where a lane reads its A consecutive values itself);
@@ -1416,7 +1416,7 @@ __device__ __forceinline__ void axis_finish_store(const Mom& m, bool weighted, i
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void k_axis_thread(const double* __restrict__ val, const double* __restrict__ sd, int64_t outer, int64_t A,
                                                      int64_t inner, int KS, double* __restrict__ partial, double* __restrict__ out_mean,
-                                                     double* __restrict__ out_std, double* __restrict__ out_err) {
+                                                     double* __restrict__ out_std, double* __restrict__ out_err, int keep_partial) {
     const int64_t n_out = outer * inner;
     const int seg = blockIdx.y;
     const int64_t jstride = static_cast<int64_t>(gridDim.x) * 256;
@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(256) void k_axis_thread(const double* __restrict__ 
             }
         }
         const Mom m = acc_finish<false>(st, WEIGHTED);
-        if (KS == 1) axis_finish_store(m, WEIGHTED, j, out_mean, out_std, out_err);
+        if (KS == 1 && !keep_partial) axis_finish_store(m, WEIGHTED, j, out_mean, out_std, out_err);
         else mom_store(partial + (static_cast<int64_t>(seg) * n_out + j) * kMomVals, m);
     }
 }
@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(256) void k_axis_thread(const double* __restrict__ 
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void k_axis_row(const double* __restrict__ val, const double* __restrict__ sd, int64_t outer, int64_t A,
                                                   int64_t inner, int KS, double* __restrict__ partial, double* __restrict__ out_mean,
-                                                  double* __restrict__ out_std, double* __restrict__ out_err) {
+                                                  double* __restrict__ out_std, double* __restrict__ out_err, int keep_partial) {
     __shared__ double red[256][kMomVals];
     const int in = static_cast<int>(inner);
     const int Tm = (256 / in) * in;                                             // active threads: a multiple of inner
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_axis_row(const double* __restrict__ val
         if (static_cast<int>(threadIdx.x) < in) {
             const Mom m = mom_load(red[threadIdx.x]);
             const int64_t j = o * inner + threadIdx.x;
-            if (KS == 1) axis_finish_store(m, WEIGHTED, j, out_mean, out_std, out_err);
+            if (KS == 1 && !keep_partial) axis_finish_store(m, WEIGHTED, j, out_mean, out_std, out_err);
             else mom_store(partial + (static_cast<int64_t>(seg) * n_out + j) * kMomVals, m);
         }
     }
@@ -1565,6 +1565,25 @@ __global__ __launch_bounds__(256) void k_axis_final_tree(const double* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) axis_finish_store(mom_load(tree[0]), weighted != 0, j, out_mean, out_std, out_err);
+}
+
+// Two groups of reduced axes with kept axes between them - the array as (outer, A1, mid, A2, inner), reduced over A1 and A2: stage 1 is the
+// one-group reduction over A1 with inner' = mid * A2 * inner, its states kept as partials; this kernel folds, per output (o, m, i), the
+// KS segments and the A2 positions (state index ((o mid + m) A2 + a2) inner + i) in a fixed order. No layout copy of the input.
+__global__ __launch_bounds__(256) void k_axis_final2(const double* __restrict__ partial, int KS, int64_t n_out1, int64_t mid, int64_t A2, int64_t inner,
+                                                     int64_t n_out2, int weighted, double* __restrict__ out_mean, double* __restrict__ out_std,
+                                                     double* __restrict__ out_err) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; j < n_out2; j += stride) {
+        const int64_t i = j % inner, om = j / inner;                            // om = o * mid + m
+        Mom m = mom_zero();
+        for (int64_t a2 = 0; a2 < A2; ++a2) {
+            const int64_t j1 = (om * A2 + a2) * inner + i;
+            for (int s = 0; s < KS; ++s) m = mom_merge(m, mom_load(partial + (static_cast<int64_t>(s) * n_out1 + j1) * kMomVals));
+        }
+        (void)mid;
+        axis_finish_store(m, weighted != 0, j, out_mean, out_std, out_err);
+    }
 }
 
 struct AxisPlan { bool row; int KS; };
@@ -1656,6 +1675,25 @@ extern "C" size_t hm_axis_statistics_workspace_bytes(int64_t outer, int64_t axis
     return p.KS > 1 ? static_cast<size_t>(p.KS) * static_cast<size_t>(outer * inner) * hm::kMomVals * sizeof(double) : 0;
 }
 
+namespace hm {
+// stage 1 of both entry points: the one-group reduction; keep_partial = leave the states in `partial` even when there is one segment
+static void launch_axis_stage1(const double* val, const double* std, int64_t outer, int64_t axis_len, int64_t inner, const AxisPlan& p,
+                               double* partial, double* out_mean, double* out_std, double* out_err, int keep_partial, hipStream_t st) {
+    const int64_t n_out = outer * inner;
+    if (!p.row) {
+        int64_t gx = (n_out + 255) / 256;
+        if (gx > (int64_t{1} << 20)) gx = int64_t{1} << 20;
+        const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(p.KS));
+        if (std) hipLaunchKernelGGL(k_axis_thread<true>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err, keep_partial);
+        else hipLaunchKernelGGL(k_axis_thread<false>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err, keep_partial);
+    } else {
+        const dim3 grid(static_cast<unsigned>(p.KS), static_cast<unsigned>(outer < 65535 ? outer : 65535));
+        if (std) hipLaunchKernelGGL(k_axis_row<true>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err, keep_partial);
+        else hipLaunchKernelGGL(k_axis_row<false>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err, keep_partial);
+    }
+}
+}  // namespace hm
+
 extern "C" int hm_axis_statistics(const double* val, const double* std, int64_t outer, int64_t axis_len, int64_t inner,
                                   double* out_mean, double* out_std, double* out_err, void* workspace, void* stream) {
     using namespace hm;
@@ -1666,23 +1704,35 @@ extern "C" int hm_axis_statistics(const double* val, const double* std, int64_t 
     double* partial = static_cast<double*>(workspace);
     hipStream_t st = as_stream(stream);
     const int64_t n_out = outer * inner;
-    if (!p.row) {
-        int64_t gx = (n_out + 255) / 256;
-        if (gx > (int64_t{1} << 20)) gx = int64_t{1} << 20;
-        const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(p.KS));
-        if (std) hipLaunchKernelGGL(k_axis_thread<true>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
-        else hipLaunchKernelGGL(k_axis_thread<false>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
-    } else {
-        const dim3 grid(static_cast<unsigned>(p.KS), static_cast<unsigned>(outer < 65535 ? outer : 65535));
-        if (std) hipLaunchKernelGGL(k_axis_row<true>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
-        else hipLaunchKernelGGL(k_axis_row<false>, grid, dim3(256), 0, st, val, std, outer, axis_len, inner, p.KS, partial, out_mean, out_std, out_err);
-    }
+    launch_axis_stage1(val, std, outer, axis_len, inner, p, partial, out_mean, out_std, out_err, 0, st);
     if (p.KS > 1) {
         if (p.KS >= 32 && n_out <= 4096)
             hipLaunchKernelGGL(k_axis_final_tree, dim3(static_cast<unsigned>(n_out)), dim3(256), 0, st, partial, p.KS, n_out, std ? 1 : 0, out_mean, out_std, out_err);
         else
             hipLaunchKernelGGL(k_axis_final, dim3(stream_grid(n_out, 256, 8)), dim3(256), 0, st, partial, p.KS, n_out, std ? 1 : 0, out_mean, out_std, out_err);
     }
+    return launch_status();
+}
+
+extern "C" size_t hm_axis_statistics2_workspace_bytes(int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner) {
+    if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1) return 0;
+    const int64_t inner1 = mid * a2 * inner;
+    const hm::AxisPlan p = hm::axis_plan(outer, a1, inner1);
+    return static_cast<size_t>(p.KS) * static_cast<size_t>(outer * inner1) * hm::kMomVals * sizeof(double);
+}
+
+extern "C" int hm_axis_statistics2(const double* val, const double* std, int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner,
+                                   double* out_mean, double* out_std, double* out_err, void* workspace, void* stream) {
+    using namespace hm;
+    if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1 || !val || !out_mean || !out_std || !workspace) return HM_EINVAL;
+    if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
+    const int64_t inner1 = mid * a2 * inner, n_out1 = outer * inner1, n_out2 = outer * mid * inner;
+    const AxisPlan p = axis_plan(outer, a1, inner1);
+    double* partial = static_cast<double*>(workspace);
+    hipStream_t st = as_stream(stream);
+    launch_axis_stage1(val, std, outer, a1, inner1, p, partial, nullptr, nullptr, nullptr, 1, st);
+    hipLaunchKernelGGL(k_axis_final2, dim3(stream_grid(n_out2, 256, 8)), dim3(256), 0, st, partial, p.KS, n_out1, mid, a2, inner, n_out2, std ? 1 : 0,
+                       out_mean, out_std, out_err);
     return launch_status();
 }
 

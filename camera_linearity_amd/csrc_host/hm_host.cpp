@@ -651,6 +651,24 @@ int hm_axis_statistics(const double* val, const double* std_, int64_t outer, int
     return HM_OK;
 }
 
+size_t hm_axis_statistics2_workspace_bytes(int64_t, int64_t, int64_t, int64_t, int64_t) { return 0; }
+int hm_axis_statistics2(const double* val, const double* std_, int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner,
+                        double* out_mean, double* out_std, double* out_err, void*, void*) {
+    if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1 || !val || !out_mean || !out_std) return HM_EINVAL;
+    const int64_t n_out = outer * mid * inner, line = a1 * a2;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n_out; ++j) {
+        const int64_t i = j % inner, m = (j / inner) % mid, o = j / (inner * mid);
+        // element (o, k1, m, k2, i) of the dense (outer, a1, mid, a2, inner) block, line position k = k1 * a2 + k2 (NumPy's order of the reduced axes)
+        auto at = [&](int64_t k) { return (((o * a1 + k / a2) * mid + m) * a2 + k % a2) * inner + i; };
+        double mean, sd, err;
+        line_statistics(line, std_ != nullptr, [&](int64_t k, double& v, double& u) { const int64_t e = at(k); v = val[e]; u = std_ ? std_[e] : 1.0; }, mean, sd, err);
+        out_mean[j] = mean; out_std[j] = sd;
+        if (out_err) out_err[j] = err;
+    }
+    return HM_OK;
+}
+
 size_t hm_channel_statistics_workspace_bytes(void) { return 64; }
 int hm_channel_statistics(const double* val, const double* std_, int64_t n, int C, double* out, void*, void*) {
     if (n < 1 || C < 1 || C > HM_MAX_CHANNELS || !val || !out || n % C != 0) return HM_EINVAL;

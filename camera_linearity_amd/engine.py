@@ -749,8 +749,8 @@ def channel_statistics(val: torch.Tensor, std: Optional[torch.Tensor]):
 def axis_statistics(val: torch.Tensor, std: Optional[torch.Tensor], axis):
     """modules/measurand.py:318-350 for any `axis` (int or tuple, NumPy conventions) -> dict(mean, std, error) shaped like NumPy's
     result (the reduced axes removed). Adjacent reduced axes are reduced in place on the dense (outer, A, inner) view
-    (hm_axis_statistics); axes that are not adjacent are first brought together (the kept axes in order, then the reduced ones:
-    a layout copy)."""
+    (hm_axis_statistics), two separate groups of them on the (outer, A1, mid, A2, inner) view (hm_axis_statistics2); only three or more
+    separate groups are first brought together (the kept axes in order, then the reduced ones: a layout copy)."""
     _require_cuda(val, "val")
     nd = val.dim()
     axes = sorted({a % nd for a in ((axis,) if isinstance(axis, int) else tuple(axis))})
@@ -763,29 +763,43 @@ def axis_statistics(val: torch.Tensor, std: Optional[torch.Tensor], axis):
         std = std.to(_F64)
     kept = [d for d in range(nd) if d not in axes]
     out_shape = tuple(val.shape[d] for d in kept)
-    if axes != list(range(axes[0], axes[-1] + 1)):
+    groups = [[axes[0]]]                                       # runs of adjacent reduced axes
+    for a_ in axes[1:]:
+        if a_ == groups[-1][-1] + 1:
+            groups[-1].append(a_)
+        else:
+            groups.append([a_])
+    if len(groups) > 2:                                        # three or more separate groups: bring them together (a layout copy)
         perm = kept + axes
         val = val.permute(perm)
         std = None if std is None else std.permute(perm)
-        lead = len(kept)
-        axes = list(range(lead, nd))
+        groups = [list(range(len(kept), nd))]
     val = val.contiguous()
     std = None if std is None else std.contiguous()
     sh = list(val.shape)
-    outer = int(np.prod(sh[:axes[0]], dtype=np.int64))
-    A = int(np.prod(sh[axes[0]:axes[-1] + 1], dtype=np.int64))
-    inner = int(np.prod(sh[axes[-1] + 1:], dtype=np.int64))
-    if outer * A * inner == 0:
+    prod = lambda lo, hi: int(np.prod(sh[lo:hi], dtype=np.int64))   # noqa: E731
+    if prod(0, len(sh)) == 0:
         raise ValueError("statistics of an empty array")
     dev = val.device
     mean = torch.empty(out_shape, dtype=_F64, device=dev)
     sd = torch.empty(out_shape, dtype=_F64, device=dev)
     err = torch.empty(out_shape, dtype=_F64, device=dev) if std is not None else None
-    ws_b = int(nat.lib.hm_axis_statistics_workspace_bytes(outer, A, inner))
-    ws = torch.empty(max(1, ws_b // 8), dtype=_F64, device=dev)
-    with _on(dev):
-        nat.check(nat.lib.hm_axis_statistics(val.data_ptr(), nat.ptr(std), outer, A, inner, mean.data_ptr(), sd.data_ptr(), nat.ptr(err),
-                                             ws.data_ptr(), _stream(dev)), "hm_axis_statistics")
+    if len(groups) == 1:
+        g = groups[0]
+        outer, A, inner = prod(0, g[0]), prod(g[0], g[-1] + 1), prod(g[-1] + 1, len(sh))
+        ws_b = int(nat.lib.hm_axis_statistics_workspace_bytes(outer, A, inner))
+        ws = torch.empty(max(1, ws_b // 8), dtype=_F64, device=dev)
+        with _on(dev):
+            nat.check(nat.lib.hm_axis_statistics(val.data_ptr(), nat.ptr(std), outer, A, inner, mean.data_ptr(), sd.data_ptr(), nat.ptr(err),
+                                                 ws.data_ptr(), _stream(dev)), "hm_axis_statistics")
+    else:                                                      # two groups with kept axes between them: reduced in place, no layout copy
+        g1, g2 = groups
+        dims = (prod(0, g1[0]), prod(g1[0], g1[-1] + 1), prod(g1[-1] + 1, g2[0]), prod(g2[0], g2[-1] + 1), prod(g2[-1] + 1, len(sh)))
+        ws_b = int(nat.lib.hm_axis_statistics2_workspace_bytes(*dims))
+        ws = torch.empty(max(1, ws_b // 8), dtype=_F64, device=dev)
+        with _on(dev):
+            nat.check(nat.lib.hm_axis_statistics2(val.data_ptr(), nat.ptr(std), *dims, mean.data_ptr(), sd.data_ptr(), nat.ptr(err),
+                                                  ws.data_ptr(), _stream(dev)), "hm_axis_statistics2")
     return {"mean": mean, "std": sd, "error": err}
 
 

@@ -307,11 +307,17 @@ int hm_channel_statistics(const double* val, const double* std /*nullable*/, int
                           double* out, void* workspace, void* stream);
 /* compute_dimension_statistics over ANY axis (modules/measurand.py:318-350 pass `axis` to NumPy's nan-reductions): the array is the
  * dense (outer, axis_len, inner) block and is reduced over its middle dimension; out_mean / out_std / out_err are outer * inner
- * float64 each (out_err nullable; NaN without std). Several reduced axes = their product when adjacent (the caller brings axes that
- * are not adjacent together with a layout copy). workspace: hm_axis_statistics_workspace_bytes() bytes (0 = none needed). */
+ * float64 each (out_err nullable; NaN without std). Several reduced axes = their product when adjacent (two separate groups:
+ * hm_axis_statistics2; three or more: the caller brings them together with a layout copy). workspace: hm_axis_statistics_workspace_bytes() bytes (0 = none needed). */
 size_t hm_axis_statistics_workspace_bytes(int64_t outer, int64_t axis_len, int64_t inner);
 int hm_axis_statistics(const double* val, const double* std /*nullable*/, int64_t outer, int64_t axis_len, int64_t inner,
                        double* out_mean, double* out_std, double* out_err /*nullable*/, void* workspace, void* stream);
+/* The same over TWO separate groups of reduced axes (e.g. axis = (0, 2) of an H x W x C image: statistics per column over rows and
+ * channels): the array is the dense (outer, a1, mid, a2, inner) block, reduced over a1 AND a2 in place - no layout copy; outputs are
+ * outer * mid * inner float64 each. workspace: hm_axis_statistics2_workspace_bytes() bytes, always required on the device build. */
+size_t hm_axis_statistics2_workspace_bytes(int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner);
+int hm_axis_statistics2(const double* val, const double* std /*nullable*/, int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner,
+                        double* out_mean, double* out_std, double* out_err /*nullable*/, void* workspace, void* stream);
 /* compute_difference / interpolate on operands that BROADCAST against each other (the reference applies NumPy broadcasting,
  * modules/measurand.py:621-681): `shape` is the broadcast result shape (ndim <= HM_MAX_DIMS), strides are in ELEMENTS with 0 on
  * broadcast axes (as hm_binary_op); an operand and its std share strides. Outputs are dense arrays of that shape. */

@@ -779,7 +779,10 @@ def test_process_linearity_thresholds_in_place(use_std, h, w, n):
 @pytest.mark.parametrize("shape,axis", [((40, 50, 3), 0), ((40, 50, 3), 1), ((40, 50, 3), 2), ((40, 50, 3), -1), ((40, 50, 3), (0, 2)),
                                         ((40, 50, 3), (1, 2)), ((40, 50, 3), (0, 1, 2)), ((5, 2000, 3), 1), ((3000, 7), 0), ((3000, 7), 1),
                                         ((2, 3, 4, 5, 6), (1, 3)), ((70000,), 0), ((1, 100000, 2), 1), ((300, 40), 0), ((9, 6), (0,)),
-                                        ((64, 64, 8), (0, 1)), ((33, 17, 20), 1)])
+                                        ((64, 64, 8), (0, 1)), ((33, 17, 20), 1),
+                                        # two separate groups of reduced axes (hm_axis_statistics2, no layout copy) and three (layout copy)
+                                        ((300, 200, 3), (0, 2)), ((6, 5, 40, 3), (0, 2)), ((6, 5, 40, 3), (1, 3)), ((4, 3, 5, 2, 7), (0, 1, 3)),
+                                        ((4, 3, 5, 2, 7), (0, 3, 4)), ((2000, 4, 2), (0, 2)), ((3, 70, 1, 9), (0, 3)), ((4, 3, 5, 2, 7), (0, 2, 4))])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_dimension_statistics_any_axis(M, shape, axis, weighted):
     """compute_dimension_statistics(axis) for single axes, adjacent and non-adjacent axis tuples, long and short axes, few and many
