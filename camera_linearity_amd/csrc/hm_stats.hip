@@ -1567,23 +1567,46 @@ __global__ __launch_bounds__(256) void k_axis_final_tree(const double* __restric
     if (threadIdx.x == 0) axis_finish_store(mom_load(tree[0]), weighted != 0, j, out_mean, out_std, out_err);
 }
 
-// Two groups of reduced axes with kept axes between them - the array as (outer, A1, mid, A2, inner), reduced over A1 and A2: stage 1 is the
-// one-group reduction over A1 with inner' = mid * A2 * inner, its states kept as partials; this kernel folds, per output (o, m, i), the
-// KS segments and the A2 positions (state index ((o mid + m) A2 + a2) inner + i) in a fixed order. No layout copy of the input.
-__global__ __launch_bounds__(256) void k_axis_final2(const double* __restrict__ partial, int KS, int64_t n_out1, int64_t mid, int64_t A2, int64_t inner,
-                                                     int64_t n_out2, int weighted, double* __restrict__ out_mean, double* __restrict__ out_std,
-                                                     double* __restrict__ out_err) {
+// Two groups of reduced axes with kept axes between them - the array as (outer, A1, mid, A2, inner), reduced over A1 and A2 with no layout
+// copy of the input. Stage 1 is the one-group reduction over the LONGER of the two (A1: inner' = mid * A2 * inner; A2: outer' = outer * A1 *
+// mid), its states kept as partials; stage 2 folds, per output (o, m, i), the R positions of the other group and the KS segments in a fixed
+// order: state index o * o_stride + m * m_stride + r * r_stride + i.
+struct Final2K { int64_t n_out1, n_out2, mid, inner, o_stride, m_stride, r_stride, R; int KS, weighted; };
+__device__ __forceinline__ int64_t final2_base(const Final2K& f, int64_t j) {
+    const int64_t i = j % f.inner, om = j / f.inner;
+    return (om / f.mid) * f.o_stride + (om % f.mid) * f.m_stride + i;
+}
+__global__ __launch_bounds__(256) void k_axis_final2(const double* __restrict__ partial, const Final2K f, double* __restrict__ out_mean,
+                                                     double* __restrict__ out_std, double* __restrict__ out_err) {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
-    for (int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; j < n_out2; j += stride) {
-        const int64_t i = j % inner, om = j / inner;                            // om = o * mid + m
+    for (int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; j < f.n_out2; j += stride) {
+        const int64_t base = final2_base(f, j);
         Mom m = mom_zero();
-        for (int64_t a2 = 0; a2 < A2; ++a2) {
-            const int64_t j1 = (om * A2 + a2) * inner + i;
-            for (int s = 0; s < KS; ++s) m = mom_merge(m, mom_load(partial + (static_cast<int64_t>(s) * n_out1 + j1) * kMomVals));
-        }
-        (void)mid;
-        axis_finish_store(m, weighted != 0, j, out_mean, out_std, out_err);
+        for (int64_t r = 0; r < f.R; ++r)
+            for (int s = 0; s < f.KS; ++s) m = mom_merge(m, mom_load(partial + (static_cast<int64_t>(s) * f.n_out1 + base + r * f.r_stride) * kMomVals));
+        axis_finish_store(m, f.weighted != 0, j, out_mean, out_std, out_err);
     }
+}
+// few outputs, many states each: one workgroup per output, thread t folds states t, t + 256, ... of the R x KS, then an LDS tree
+__global__ __launch_bounds__(256) void k_axis_final2_tree(const double* __restrict__ partial, const Final2K f, double* __restrict__ out_mean,
+                                                          double* __restrict__ out_std, double* __restrict__ out_err) {
+    __shared__ double tree[256][kMomVals];
+    const int64_t j = blockIdx.x, base = final2_base(f, j), total = f.R * f.KS;
+    Mom m = mom_zero();
+    for (int64_t q = threadIdx.x; q < total; q += 256) {
+        const int64_t r = q / f.KS, sgm = q % f.KS;
+        m = mom_merge(m, mom_load(partial + (sgm * f.n_out1 + base + r * f.r_stride) * kMomVals));
+    }
+    mom_store(tree[threadIdx.x], m);
+    __syncthreads();
+    for (int span = 128; span > 0; span >>= 1) {
+        if (static_cast<int>(threadIdx.x) < span) {
+            const Mom r = mom_merge(mom_load(tree[threadIdx.x]), mom_load(tree[threadIdx.x + span]));
+            mom_store(tree[threadIdx.x], r);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) axis_finish_store(mom_load(tree[0]), f.weighted != 0, j, out_mean, out_std, out_err);
 }
 
 struct AxisPlan { bool row; int KS; };
@@ -1714,11 +1737,28 @@ extern "C" int hm_axis_statistics(const double* val, const double* std, int64_t 
     return launch_status();
 }
 
+namespace hm {
+// which group stage 1 reduces (the longer one), the (outer, A, inner) view it sees and the index map of stage 2
+struct Axis2Plan { int64_t outer1, A, inner1; AxisPlan p; Final2K f; };
+static Axis2Plan axis2_plan(int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner) {
+    Axis2Plan q{};
+    if (a1 >= a2) {            // stage 1 over A1: state index ((o mid + m) A2 + r) inner + i
+        q.outer1 = outer; q.A = a1; q.inner1 = mid * a2 * inner;
+        q.f.o_stride = mid * a2 * inner; q.f.m_stride = a2 * inner; q.f.r_stride = inner; q.f.R = a2;
+    } else {                   // stage 1 over A2: state index ((o A1 + r) mid + m) inner + i
+        q.outer1 = outer * a1 * mid; q.A = a2; q.inner1 = inner;
+        q.f.o_stride = a1 * mid * inner; q.f.m_stride = inner; q.f.r_stride = mid * inner; q.f.R = a1;
+    }
+    q.p = axis_plan(q.outer1, q.A, q.inner1);
+    q.f.n_out1 = q.outer1 * q.inner1; q.f.n_out2 = outer * mid * inner; q.f.mid = mid; q.f.inner = inner; q.f.KS = q.p.KS;
+    return q;
+}
+}  // namespace hm
+
 extern "C" size_t hm_axis_statistics2_workspace_bytes(int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner) {
     if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1) return 0;
-    const int64_t inner1 = mid * a2 * inner;
-    const hm::AxisPlan p = hm::axis_plan(outer, a1, inner1);
-    return static_cast<size_t>(p.KS) * static_cast<size_t>(outer * inner1) * hm::kMomVals * sizeof(double);
+    const hm::Axis2Plan q = hm::axis2_plan(outer, a1, mid, a2, inner);
+    return static_cast<size_t>(q.p.KS) * static_cast<size_t>(q.f.n_out1) * hm::kMomVals * sizeof(double);
 }
 
 extern "C" int hm_axis_statistics2(const double* val, const double* std, int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner,
@@ -1726,13 +1766,15 @@ extern "C" int hm_axis_statistics2(const double* val, const double* std, int64_t
     using namespace hm;
     if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1 || !val || !out_mean || !out_std || !workspace) return HM_EINVAL;
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
-    const int64_t inner1 = mid * a2 * inner, n_out1 = outer * inner1, n_out2 = outer * mid * inner;
-    const AxisPlan p = axis_plan(outer, a1, inner1);
+    Axis2Plan q = axis2_plan(outer, a1, mid, a2, inner);
+    q.f.weighted = std ? 1 : 0;
     double* partial = static_cast<double*>(workspace);
     hipStream_t st = as_stream(stream);
-    launch_axis_stage1(val, std, outer, a1, inner1, p, partial, nullptr, nullptr, nullptr, 1, st);
-    hipLaunchKernelGGL(k_axis_final2, dim3(stream_grid(n_out2, 256, 8)), dim3(256), 0, st, partial, p.KS, n_out1, mid, a2, inner, n_out2, std ? 1 : 0,
-                       out_mean, out_std, out_err);
+    launch_axis_stage1(val, std, q.outer1, q.A, q.inner1, q.p, partial, nullptr, nullptr, nullptr, 1, st);
+    if (q.f.R * q.f.KS >= 64 && q.f.n_out2 <= 4096)
+        hipLaunchKernelGGL(k_axis_final2_tree, dim3(static_cast<unsigned>(q.f.n_out2)), dim3(256), 0, st, partial, q.f, out_mean, out_std, out_err);
+    else
+        hipLaunchKernelGGL(k_axis_final2, dim3(stream_grid(q.f.n_out2, 256, 8)), dim3(256), 0, st, partial, q.f, out_mean, out_std, out_err);
     return launch_status();
 }
 

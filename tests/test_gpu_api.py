@@ -782,7 +782,9 @@ def test_process_linearity_thresholds_in_place(use_std, h, w, n):
                                         ((64, 64, 8), (0, 1)), ((33, 17, 20), 1),
                                         # two separate groups of reduced axes (hm_axis_statistics2, no layout copy) and three (layout copy)
                                         ((300, 200, 3), (0, 2)), ((6, 5, 40, 3), (0, 2)), ((6, 5, 40, 3), (1, 3)), ((4, 3, 5, 2, 7), (0, 1, 3)),
-                                        ((4, 3, 5, 2, 7), (0, 3, 4)), ((2000, 4, 2), (0, 2)), ((3, 70, 1, 9), (0, 3)), ((4, 3, 5, 2, 7), (0, 2, 4))])
+                                        ((4, 3, 5, 2, 7), (0, 3, 4)), ((2000, 4, 2), (0, 2)), ((3, 70, 1, 9), (0, 3)), ((4, 3, 5, 2, 7), (0, 2, 4)),
+                                        # the second group longer than the first (stage 1 then reduces IT), few outputs with many states each (tree fold)
+                                        ((3, 4, 5000), (0, 2)), ((64, 8, 4096), (0, 2)), ((2, 3, 500, 2), (0, 2)), ((300, 2, 4000), (0, 2)), ((4096, 2, 3), (0, 2))])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_dimension_statistics_any_axis(M, shape, axis, weighted):
     """compute_dimension_statistics(axis) for single axes, adjacent and non-adjacent axis tuples, long and short axes, few and many
