@@ -215,3 +215,29 @@ def test_row_tile_set_two_ranks_assembly(shared):
     assert np.array_equal(gval, whole["val"].cpu().numpy())
     assert np.array_equal(gstd, whole["std"].cpu().numpy())
     assert path == ("shared-memory image" if shared else "tensor sends over the CPU group"), path
+
+
+def test_example_one_image_on_n_gpus_same_image_for_any_rank_count():
+    """examples/merge_one_image_on_n_gpus.py (the user-level recipe: RowTileSet + a gloo group, no collective on the data path) with one
+    process and with three ranks sharing the GPU: the assembled image has the same mean to the last printed digit, the three-rank run
+    went through the shared-memory image."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pathlib
+    import re
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    ex = str(root / "examples" / "merge_one_image_on_n_gpus.py")
+    size = ["--frames", "5", "--height", "1024", "--width", "640", "--tiles", "8", "--std"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    one = subprocess.run([sys.executable, ex] + size, capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), ex, "--share-device"] + size, capture_output=True, text=True, timeout=600, env=env)
+    assert three.returncode == 0, three.stderr[-2000:]
+    pat = re.compile(r"val \((\d+), (\d+), 3\) mean ([0-9.]+), std mean ([0-9.e+-]+)")
+    m1, m3 = pat.search(one.stdout), pat.search(three.stdout)
+    assert m1 and m3, (one.stdout, three.stdout)
+    assert m1.groups() == m3.groups() and m1.group(1) == "1024"
+    assert "on 3 rank(s)" in three.stdout and "shared-memory image" in three.stdout and "pinned image" in one.stdout
