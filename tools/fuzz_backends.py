@@ -28,6 +28,7 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--log", default=None)
 ap.add_argument("--one", default=None, help="<generator>:<seed> - re-run one reported case and print both sides of the first mismatch in full")
 ap.add_argument("--specials", type=float, default=0.3, help="share of cases whose float operands get NaN / +-inf / +-0 sprinkled in")
+ap.add_argument("--scale", type=int, default=1, help="multiplies the image sizes of the merge / linearity / Welford / statistics generators (streaming kernels over many groups)")
 ap.add_argument("--self-check", action="store_true", help="host build against itself (no GPU): exercises this script only")
 args = ap.parse_args()
 dev = torch.device("cpu" if args.self_check else "cuda:0")
@@ -124,9 +125,9 @@ def icrf_tables(rng, c):
 def case_merge(rng):
     c = int(rng.choice([1, 2, 3, 3, 3, 4]))
     n = int(rng.choice([1, 2, 3, 5, 7, 7, 8, 9, 15, 16, 17, 20, 32, 33, 40]))
-    h, w = int(rng.integers(1, 48)), int(rng.integers(1, 130))
+    h, w = int(rng.integers(1, 48 * args.scale)), int(rng.integers(1, 130 * args.scale))
     if rng.random() < 0.3:                                             # whole 128-element groups: the streaming kernels, not only the generic tail
-        h, w = int(rng.integers(8, 40)), 128 * int(rng.integers(1, 4))
+        h, w = int(rng.integers(8, 40 * args.scale)), 128 * int(rng.integers(1, 4 * args.scale))
     f64 = rng.random() < 0.25
     with_std = rng.random() < 0.5
     use_dark = rng.random() < 0.4
@@ -237,7 +238,7 @@ def case_unary(rng):
 
 def case_stats(rng):
     nd = int(rng.integers(1, 5))
-    shape = tuple(int(rng.integers(1, 24)) for _ in range(nd))
+    shape = tuple(int(rng.integers(1, 24 * (args.scale if nd <= 3 else 1))) for _ in range(nd))
     if rng.random() < 0.3:
         shape = shape[:-1] + (int(rng.choice([3, 3, 1, 4])),)
     x = rng.normal(size=shape) * 3 + rng.uniform(-100, 100)
@@ -392,9 +393,9 @@ def case_linearity(rng):
     """ExposureSeries.process_linearity's fused launch: in-place thresholds, every pair's absolute / relative difference statistics."""
     c = int(rng.choice([1, 3, 3, 4]))
     n = int(rng.integers(2, 8))
-    h, w = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+    h, w = int(rng.integers(1, 40 * args.scale)), int(rng.integers(1, 60 * args.scale))
     if rng.random() < 0.3:
-        h, w = int(rng.integers(16, 64)), 64 * int(rng.integers(1, 5))
+        h, w = int(rng.integers(16, 64 * args.scale)), 64 * int(rng.integers(1, 5 * args.scale))
     rad = rng.random((h, w, c)) * 4
     t = np.sort(rng.uniform(0.01, 1.0, size=n))
     vals = [np.clip(rad * ti + rng.normal(size=rad.shape) * 0.01, 0, None) for ti in t]
@@ -412,10 +413,15 @@ def case_linearity(rng):
     sb = None if stds is None else [Hh(v) for v in stds]
     ra = engine.pairs_statistics(va, sa, pairs, to_host=True, thresholds=thr)
     rb = heng.pairs_statistics(vb, sb, pairs, to_host=True, thresholds=thr)
+    # Without thresholds the relative difference is heavy-tailed (y near 0: values 1e4 and more beside a spread of 1e-2). The device's
+    # one-pass moments take their first shift K from a lane's first element: when that one is such an outlier, the lane's first 64-element
+    # block carries eps (K - mean)^2 / sigma^2 of relative error (seen: up to 1e-7 on the std) where the host's two-pass form has eps n.
+    # The reference's own use thresholds first (modules/exposure_series.py:431): bounded data, 1e-9.
+    std_tol = 1e-9 if thr is not None else 1e-6
     for q, ((aa, ar), (ba, br)) in enumerate(zip(ra, rb)):
         for nm, x_, y_ in (("abs", aa, ba), ("rel", ar, br)):
             for key in y_:
-                compare(f"pair{q}.{nm}.{key}", x_[key], y_[key], 1e-9 if key != "mean" else 1e-11, atol=1e-13 * 4)
+                compare(f"pair{q}.{nm}.{key}", x_[key], y_[key], std_tol if key != "mean" else max(1e-11, std_tol * 1e-2), atol=1e-13 * 4)
     if thr is not None:                                                # the thresholded frames (written in place) must agree exactly
         for i in range(n):
             compare(f"thresholded[{i}]", va[i], vb[i], None)
@@ -428,7 +434,7 @@ def case_welford(rng):
     """hm_welford_update / hm_welford_finalize: mean / M2 state after several launches and the uint8 result frames - bit-exact (the device's
     division by the frame count is proven equal to the IEEE quotient in its accepted range and falls back to it outside)."""
     c = int(rng.choice([1, 3, 3, 4]))
-    h, w = int(rng.integers(1, 30)), int(rng.integers(1, 40))
+    h, w = int(rng.integers(1, 30 * args.scale)), int(rng.integers(1, 40 * args.scale))
     n = int(rng.integers(1, 80))
     use_m2 = rng.random() < 0.7
     use_icrf = rng.random() < 0.5
