@@ -164,16 +164,35 @@ def case_merge(rng):
             kw.update(flat_std=0.002 * (1 + rng.random((h, w, c))), ff_std_mean=list(rng.uniform(0.001, 0.003, size=c)))
     kw["want_sum_w"] = bool(sum_w)
 
-    def run(eng, conv):
+    # a third of the cases: the DEVICE merges a row tile (with the median's halo rows) through a forced kernel path - the generic kernel
+    # (variant -1) or chunks of 2 / 5 frames per launch (-2 / -5) - and must still give the rows of the host build's whole-image result
+    tile = None
+    if rng.random() < 0.33 and h >= 2:
+        r0 = int(rng.integers(0, h - 1)); r1 = int(rng.integers(r0 + 1, h + 1))
+        halo = (k // 2) if "darks" in kw else 0
+        tile = (r0, r1, max(0, r0 - halo), min(h, r1 + halo))
+    dev_variant = int(rng.choice([0, 0, -1, -2, -5])) if rng.random() < 0.4 else 0
+    desc += f" tile={tile} variant={dev_variant}"
+
+    def run(eng, conv, tl, variant):
         k2 = dict(kw)
+        rows = slice(None) if tl is None else slice(tl[2], tl[3])
+        out_rows = slice(None) if tl is None else slice(tl[0], tl[1])
         for name in ("flat", "flat_std"):
             if name in k2:
-                k2[name] = conv(k2[name])
+                k2[name] = conv(k2[name][out_rows])
         if "darks" in k2:
-            k2["darks"] = [conv(x) for x in k2["darks"]]
-        return eng.merge([conv(f) for f in frames], list(t), g, d if with_std else None, [conv(s) for s in stds] if with_std else None, **k2)
+            k2["darks"] = [None if x is None else conv(x[rows]) for x in k2["darks"]]
+        if tl is not None:
+            k2.update(height=h, row0=tl[0], rows=tl[1] - tl[0], buf_row0=tl[2])
+        if variant:
+            k2["variant"] = variant
+        return eng.merge([conv(f[rows]) for f in frames], list(t), g, d if with_std else None,
+                         [conv(s[rows]) for s in stds] if with_std else None, **k2)
 
-    a, b = run(engine, D), run(heng, Hh)
+    a, b = run(engine, D, tile, dev_variant), run(heng, Hh, None, 0)
+    if tile is not None:
+        b = {key: v[tile[0]:tile[1]] for key, v in b.items()}
     exact = not f64                                                    # float64 frames evaluate exp(): two math libraries
     for key in b:                                                      # (the std of float64 frames amplifies exp()'s last bit through (dw g + w dg)/S - dw w g/S^2)
         compare(f"{key}", a[key], b[key], None if exact else (1e-9 if key == "std" else 1e-12))
