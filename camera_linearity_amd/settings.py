@@ -22,6 +22,8 @@ UPPER_LIN_LIM = 250            # :69
 ICRF_CALIBRATED_FILE = None    # text table (BITS, C) read by process_HDR_image(ICRF=None), exposure_series.py:406-407
 DEFAULT_DARK_PATH = None       # directory of dark frames, exposure_series.py:409 / image_set.py:170
 DEFAULT_FLAT_PATH = None       # directory of flat fields, image_set.py:146-155
+DATA_PATH = None               # directory of the text tables read_txt_to_array loads by name (global_settings.py: the data directory)
+DATAPOINTS = BITS              # samples per ICRF curve after interpolate_data (global_settings.py: 'final datapoints'; equal to BITS = no resampling)
 
 
 def configure(**kw):

@@ -485,7 +485,54 @@ def case_energy():
          pairs_plain=np.stack(pairs_plain), pairs_std=np.stack(pairs_std), abs_plain=abs_plain, abs_std=abs_std)
 
 
+def case_helpers():
+    """The host-side helpers of modules/general_functions.py that the path's callers use (exposure_series.py:434 map_linearity_limits,
+    ICRF_calibration_exposure.py choose_evenly_spaced_points / predict_output_shape / nanaverage / weighted_avg_and_std, measurand.py
+    is_broadcastable, weighted_percentile), run as written on seeded inputs."""
+    import general_functions as gf
+    rng = np.random.default_rng(21)
+    out = {}
+    shapes = [((3, 4, 5), (4, 5)), ((3, 4, 5), (3, 1, 5)), ((2, 3), (3, 2)), ((7,), (1,)), ((5, 1, 6), (4, 6)), ((5, 2, 6), (4, 6))]
+    out["bc_shapes_a"] = np.array([list(a) + [0] * (3 - len(a)) for a, _ in shapes]); out["bc_len_a"] = np.array([len(a) for a, _ in shapes])
+    out["bc_shapes_b"] = np.array([list(b) + [0] * (3 - len(b)) for _, b in shapes]); out["bc_len_b"] = np.array([len(b) for _, b in shapes])
+    out["bc_result"] = np.array([gf.is_broadcastable(a, b) for a, b in shapes])
+    img = rng.random((23, 31, 3))
+    out["ces_in"] = img
+    out["ces_5"] = gf.choose_evenly_spaced_points(img, 5)
+    out["ces_4_7"] = gf.choose_evenly_spaced_points(img, 4, 7)
+    out["pos"] = np.array([gf.predict_output_shape((23, 31), 5), gf.predict_output_shape((23, 31), 4, 7), gf.predict_output_shape((1, 1), 9)])
+    v = rng.normal(size=200) * 2 + 1
+    w = rng.random(200) + 0.1
+    out["was_v"], out["was_w"] = v, w
+    out["was"] = np.array(gf.weighted_avg_and_std(v, w))
+    out["was_none"] = np.array(gf.weighted_avg_and_std(v, None))
+    a = rng.random((6, 7, 4)); a[rng.random(a.shape) < 0.2] = np.nan
+    ww = rng.random((6, 7, 4)); ww[rng.random(ww.shape) < 0.2] = np.nan
+    ww[:, 3, 1] = np.nan                                                     # a line without any valid weight -> NaN
+    out["na_v"], out["na_w"] = a, ww
+    with np.errstate(all="ignore"):
+        out["na_axis0"] = gf.nanaverage(a, ww, 0)
+        out["na_axis01"] = gf.nanaverage(a, ww, (0, 1))
+        out["na_axis2"] = gf.nanaverage(a, ww, 2)
+    pv = rng.normal(size=101)
+    pw = rng.integers(1, 5, size=101).astype(np.float64)
+    out["wp_v"], out["wp_w"] = pv, pw
+    out["wp_default"] = gf.weighted_percentile(pv)
+    out["wp_weighted"] = gf.weighted_percentile(pv, np.array([5.0, 50.0, 95.0]), pw)
+    icrf = make_icrf((2.2, 2.0, 1.8))[0]
+    out["mll_icrf"] = icrf
+    lo, up = gf.map_linearity_limits(None, None, icrf); out["mll_none_icrf"] = np.stack([lo, up])
+    lo, up = gf.map_linearity_limits(10, 20, icrf); out["mll_10_20_icrf"] = np.stack([lo, up])
+    lo, up = gf.map_linearity_limits(None, None, None); out["mll_none_none"] = np.stack([lo, up])
+    lo, up = gf.map_linearity_limits(7, 3, None); out["mll_7_3_none"] = np.stack([lo, up])
+    save("helpers", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                                    # python make_golden.py helpers [energy ...]: only those cases
+        for name in sys.argv[1:]:
+            globals()["case_" + name]()
+        raise SystemExit(0)
     case_identity()
     case_std()
     case_full()
@@ -495,3 +542,4 @@ if __name__ == "__main__":
     case_operators()
     case_welford()
     case_energy()
+    case_helpers()
