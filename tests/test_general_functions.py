@@ -51,3 +51,22 @@ def test_map_linearity_limits_and_icrf_file(golden, tmp_path):
     np.testing.assert_allclose(gf.read_txt_to_array("ICRF_calibrated.txt", str(tmp_path)), icrf, rtol=1e-15)
     with pytest.raises(ImportError, match="frames_from_capture"):
         next(gf.video_frame_generator(tmp_path / "missing.avi"))
+
+
+def test_global_settings_class_is_a_view_of_settings():
+    from camera_linearity_amd import settings
+    from camera_linearity_amd.global_settings import GlobalSettings as gs
+    assert gs.BITS == 256 and gs.MAX_DN == 255 and gs.NUM_OF_CHS == 3 and gs.CH_STR[2] == "Red"
+    old = settings.DARK_THRESHOLD
+    try:
+        settings.configure(DARK_THRESHOLD=0.123)
+        assert gs.DARK_THRESHOLD == 0.123                   # read at access time
+        gs.DARK_THRESHOLD = 0.2                             # assignment configures
+        assert settings.DARK_THRESHOLD == 0.2
+        with pytest.raises(NotImplementedError):
+            gs.BIT_DEPTH = 12                               # the kernels are built for 8-bit DNs
+    finally:
+        settings.configure(DARK_THRESHOLD=old)
+    with pytest.raises(AttributeError, match="PCA_FILES"):
+        gs.PCA_FILES
+    assert "LOWER_LIN_LIM" in dir(gs)
