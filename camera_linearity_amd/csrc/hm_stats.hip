@@ -275,7 +275,10 @@ __device__ __forceinline__ Mom mom_zero() { return Mom{0.0, 0.0, 0.0, 0.0, 0.0, 
 // (S0 = sum w, S1 = sum w (v - K), S2 = sum w (v - K)^2: three FMAs per element, no division), an element that NumPy's nan-functions
 // would skip enters with weight 0 and deviation 0 (selects, no branch), and the block is folded into the running (W, mean, M2) with
 // Chan's formula when the LOOP COUNTER says so (wave-uniform) - two divisions per block instead of two per element. K tracks the data
-// (until the first fold it is the first valid element), so S2 - S1^2 / S0 differences nothing large.
+// (until the first fold it is the first valid element), so S2 - S1^2 / S0 differences nothing large. The FIRST fold comes early - after a
+// lane's first iteration (2-4 elements) - because that first element may be an outlier that barely counts (a relative difference against
+// y ~ 0 with its huge std: weight ~ 0): as the shift of a whole 64-element block it cost eps (K - mean)^2 / sigma^2 = 1e-7 on the std
+// (tools/fuzz_backends.py --scale 6); after two elements the weighted mean is already the ordinary one.
 #ifndef HM_MOM_BLOCK
 #define HM_MOM_BLOCK 64      // round 4: 8 -> 64. A fold is two reciprocals, a dozen multiplies and a branch per state; the all-pairs kernel (FP64-VALU
 #endif                       // bound, two states per wave) went 2 673 -> 2 440 us with std and 1 429 -> 1 210 us without on one box (16: 2 548 / 1 305,
@@ -569,7 +572,7 @@ __device__ __forceinline__ Mom stats_loop(const double* val, const double* sd, i
         }
         acc_add(st, v, w, s, WEIGHTED, ok);
     };
-    auto fold = [&]() { if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) acc_fold<false>(st); };
+    auto fold = [&]() { if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1 || it == 0) acc_fold<false>(st); };   // (it == 0: early_fold, see MomAcc)
     auto whole = [&](int64_t b) { return b + (UN - 1) * stride + 64 <= n; };
     auto load = [&](int64_t b, double (&vv)[UN], double (&sv)[UN]) {
 #pragma unroll
@@ -734,7 +737,7 @@ __device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mul
         acc_add_pair<STD, LEAN>(st[0], av, wa, as);
         acc_add_pair<STD, LEAN>(st[1], rv, wr, rs);
     }
-    if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }   // every kMomBlock elements, whatever UN
+    if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1 || it == 0) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }   // every kMomBlock elements, whatever UN (+ the early fold)
 }
 
 // whole chunks only (all 64 lanes active): the lean body once every lane of the wave has seen a valid element of both differences
@@ -1443,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_axis_thread(const double* __restrict__ 
                 acc_add(st, v[u], w, sv[u], WEIGHTED, true);
             }
             it += UNR;
-            if ((it & (kMomBlock - 1)) == 0) acc_fold<false>(st);
+            if ((it & (kMomBlock - 1)) == 0 || it == UNR) acc_fold<false>(st);
         }
         if (k < A) {                                                            // the last 1-3 positions: loads together, missing ones at weight 0
             double v[UNR - 1], sv[UNR - 1];
@@ -1502,7 +1505,7 @@ __global__ __launch_bounds__(256) void k_axis_row(const double* __restrict__ val
                     acc_add(st, v[u], w, sv[u], WEIGHTED, true);
                 }
                 it += UNR;
-                if ((it & (kMomBlock - 1)) == 0) acc_fold<false>(st);
+                if ((it & (kMomBlock - 1)) == 0 || it == UNR) acc_fold<false>(st);
             }
             for (; e < e_hi; e += Tm) {
                 const double v = pv[e];

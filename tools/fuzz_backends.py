@@ -436,7 +436,7 @@ def case_linearity(rng):
     # one-pass moments take their first shift K from a lane's first element: when that one is such an outlier, the lane's first 64-element
     # block carries eps (K - mean)^2 / sigma^2 of relative error (seen: up to 1e-7 on the std) where the host's two-pass form has eps n.
     # The reference's own use thresholds first (modules/exposure_series.py:431): bounded data, 1e-9.
-    std_tol = 1e-9 if thr is not None else 1e-6
+    std_tol = 1e-9 if thr is not None else float(__import__('os').environ.get('FUZZ_LIN_TOL', '1e-6'))
     for q, ((aa, ar), (ba, br)) in enumerate(zip(ra, rb)):
         for nm, x_, y_ in (("abs", aa, ba), ("rel", ar, br)):
             for key in y_:
