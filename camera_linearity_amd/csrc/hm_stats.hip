@@ -737,7 +737,9 @@ __device__ __forceinline__ void pair_process(MomAcc (&st)[2], int it, double mul
         acc_add_pair<STD, LEAN>(st[0], av, wa, as);
         acc_add_pair<STD, LEAN>(st[1], rv, wr, rs);
     }
-    if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1 || it == 0) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }   // every kMomBlock elements, whatever UN (+ the early fold)
+    // every kMomBlock elements, whatever UN; weighted: + the early fold (unweighted an outlier counts in full and sets the scale of the
+    // variance itself - and the extra condition cost the unweighted all-pairs kernel 3.5 %: 1 160 -> 1 203 us)
+    if ((it & (kMomBlock / UN - 1)) == kMomBlock / UN - 1 || (STD && it == 0)) { acc_fold<true>(st[0]); acc_fold<true>(st[1]); }
 }
 
 // whole chunks only (all 64 lanes active): the lean body once every lane of the wave has seen a valid element of both differences
