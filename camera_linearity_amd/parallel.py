@@ -26,17 +26,28 @@ import numpy as np
 import torch
 
 
-def row_tile_bounds(height: int, world_size: int) -> List[Tuple[int, int]]:
-    """Rank r owns rows [r*H/G, (r+1)*H/G) (integer floor): contiguous, disjoint, covering, balanced to 1 row."""
+def row_tile_bounds(height: int, world_size: int, row_elems: Optional[int] = None) -> List[Tuple[int, int]]:
+    """Rank r owns rows [r*H/G, (r+1)*H/G) (integer floor): contiguous, disjoint, covering, balanced to 1 row.
+    row_elems = W * C: when it is odd, tiles start on EVEN rows (balanced to 2 rows), so that a tile and its halo can always start an even
+    number of elements into the image (halo_bounds)."""
     if height < 0 or world_size < 1:
         raise ValueError("height >= 0 and world_size >= 1 required")
-    return [((r * height) // world_size, ((r + 1) * height) // world_size) for r in range(world_size)]
+    cut = [(r * height) // world_size for r in range(world_size + 1)]
+    if row_elems is not None and row_elems % 2 == 1:
+        cut = [c & ~1 for c in cut[:-1]] + [height]
+    return [(cut[r], cut[r + 1]) for r in range(world_size)]
 
 
-def halo_bounds(row0: int, row1: int, height: int, median_k: int = 0) -> Tuple[int, int]:
-    """Input rows a tile must hold: its own rows plus floor(k/2) rows either side, clipped to the image."""
+def halo_bounds(row0: int, row1: int, height: int, median_k: int = 0, row_elems: Optional[int] = None) -> Tuple[int, int]:
+    """Input rows a tile must hold: its own rows plus floor(k/2) rows either side, clipped to the image.
+    row_elems = W * C of the image: when it is odd, the rows above the tile are made an EVEN number (one more row, if the image has
+    it) - the streaming kernels read element pairs and need the tile's first element, (row0 - buffer row0) * W * C elements into the
+    buffer, at an even offset; an odd one sends the whole tile through the one-element-per-thread generic kernel (same bits, 3-4 x slower)."""
     r = median_k // 2 if median_k else 0
-    return max(0, row0 - r), min(height, row1 + r)
+    b0, b1 = max(0, row0 - r), min(height, row1 + r)
+    if row_elems is not None and row_elems % 2 == 1 and (row0 - b0) % 2 == 1 and b0 > 0:
+        b0 -= 1
+    return b0, b1
 
 
 def stacks_for_rank(n_stacks: int, rank: int, world_size: int) -> List[int]:
@@ -64,9 +75,10 @@ def merge_row_tile(frames_host: Sequence[np.ndarray], exposures, icrf, icrf_diff
     row_tile_bounds() gives this rank (a rank that owns several tiles calls once per tile)."""
     from . import engine
     H = frames_host[0].shape[0]
-    r0, r1 = row_tile_bounds(H, world_size)[rank] if tile is None else tile
+    row_elems = int(np.prod(frames_host[0].shape[1:], dtype=np.int64))           # W * C: odd -> even tile starts and halo (halo_bounds)
+    r0, r1 = row_tile_bounds(H, world_size, row_elems)[rank] if tile is None else tile
     use_hot = darks_host is not None and any(d is not None for d in darks_host)
-    b0, b1 = halo_bounds(r0, r1, H, median_k if use_hot else 0)
+    b0, b1 = halo_bounds(r0, r1, H, median_k if use_hot else 0, row_elems)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     if r1 == r0:
@@ -209,9 +221,11 @@ class RowTileSet:
     `assemble()` puts the tiles of all ranks into ONE host image on `dst`: a shared-memory image every rank copies its own rows
     into (SharedHostImage), or - fallback - tensor sends over the CPU (gloo) group. There is no GPU<->GPU traffic on this path."""
 
-    def __init__(self, height: int, n_tiles: int, rank: int = 0, world_size: int = 1, median_k: int = 0):
+    def __init__(self, height: int, n_tiles: int, rank: int = 0, world_size: int = 1, median_k: int = 0, row_elems: Optional[int] = None):
+        """row_elems = W * C (optional): lets input_rows() keep a tile's first element at an even offset for odd W * C (halo_bounds)."""
+        self.row_elems = row_elems
         self.height, self.n_tiles, self.rank, self.world = height, n_tiles, rank, world_size
-        self.bounds = row_tile_bounds(height, n_tiles)
+        self.bounds = row_tile_bounds(height, n_tiles, row_elems)
         self.mine = tiles_for_rank(n_tiles, rank, world_size)
         self.median_k = median_k
         self.plans = {}
@@ -221,7 +235,7 @@ class RowTileSet:
 
     def input_rows(self, tile: int) -> Tuple[int, int]:
         r0, r1 = self.bounds[tile]
-        return halo_bounds(r0, r1, self.height, self.median_k)
+        return halo_bounds(r0, r1, self.height, self.median_k, self.row_elems)
 
     def add_tile(self, tile: int, frames, exposures, icrf, icrf_diff=None, stds=None, **kw):
         """frames / stds / darks: device tensors covering input_rows(tile); flat / flat_std cover the tile's own rows."""

@@ -51,7 +51,7 @@ def main():
     N, H, W, C = a.frames, a.height, a.width, 3
     icrf, diff = synthetic_icrf()
     t = synthetic_exposures(N)
-    tiles = parallel.RowTileSet(H, a.tiles, rank=rank, world_size=world, median_k=0)
+    tiles = parallel.RowTileSet(H, a.tiles, rank=rank, world_size=world, median_k=0, row_elems=W * C)   # (row_elems: odd W * C -> tiles start on even rows)
     gen = np.random.default_rng(7)                            # the same stream on every rank: each cuts its own rows out of the same image
     k = 255.0 / (4.0 * t[N // 2])
     for tile in range(a.tiles):

@@ -127,6 +127,11 @@ typedef struct hm_merge_args {
     int64_t  width;               /* W                                                              */
     int64_t  row0, rows;          /* output rows of this call                                       */
     int64_t  buf_row0, buf_rows;  /* image rows covered by the input buffers                        */
+                                  /* (the streaming kernels read element pairs: they need the call's first input element,
+                                     (row0 - buf_row0) * W * C elements into every frame buffer, at an EVEN offset - and float64
+                                     frames / stds / outputs / flat buffers 16-byte aligned there; otherwise the call runs in the
+                                     one-element-per-thread generic kernel: same bits, 3-4 x slower. Only an odd W * C with an odd
+                                     number of halo rows above the tile breaks this: give such a tile one more row above.)          */
 
     const uint8_t* const* frames_u8;   /* [host] N device pointers to uint8 DN frames, or NULL       */
     const double*  const* frames_f64;  /* [host] N device pointers to float64 value frames, or NULL  */

@@ -1449,3 +1449,36 @@ def test_full_size_device_output_equals_the_host_build(eng, cfg):
         assert got.shape == h_out[key].shape and got.shape[0] == (1024 if cfg == "cfg4tile" else 4096)
         assert torch.equal(got, h_out[key]), (cfg, key, int((got != h_out[key]).sum()))
         assert bool(torch.isfinite(got).all())
+
+
+def test_odd_width_tiles_keep_the_streaming_kernels(eng):
+    """An image with an odd W * C (333 x 3) cut into row tiles with the k = 3 median's halo: with RowTileSet(row_elems=W * C) every tile
+    starts an even number of elements into its buffer and is merged by the streaming kernel (the library's own dispatch says which); without
+    it the odd-offset tiles fall to merge_generic. Either way the tiles are the whole image's rows, bit for bit."""
+    from camera_linearity_amd import parallel
+    rng = np.random.default_rng(9)
+    n, H, W = 7, 600, 333
+    frames, stds, t = orc.synthetic_stack(70, n, H, W, with_std=True)
+    icrf, diff = orc.synthetic_icrf()
+    dark = rng.integers(0, 10, (H, W, 3)).astype(np.uint8); dark[rng.random(dark.shape) < 0.01] = 220
+    fd, sd, dd = [dev(f) for f in frames], [dev(s) for s in stds], dev(dark)
+    whole = eng.merge(fd, t, icrf, diff, sd, darks=[dd] * n, dark_min=[100] * n, median_k=3)
+    for row_elems, expect_generic in ((W * 3, False), (None, True)):
+        tiles = parallel.RowTileSet(H, 5, median_k=3, row_elems=row_elems)
+        saw_generic = False
+        for tile in range(5):
+            b0, b1 = tiles.input_rows(tile)
+            # (.clone(): a buffer of the tile's own, as on another GPU - a view into the whole image would inherit ITS alignment)
+            tiles.add_tile(tile, [f[b0:b1].clone() for f in fd], t, icrf, diff, [s[b0:b1].clone() for s in sd], darks=[dd[b0:b1].clone()] * n,
+                           dark_min=[100] * n, median_k=3)
+            kern = tiles.plans[tile].kernels
+            saw_generic = saw_generic or kern.startswith("merge_generic")
+            if row_elems is not None:
+                assert kern.startswith("merge_u8_fast_std"), (tile, kern)
+        assert saw_generic == expect_generic
+        tiles.launch()
+        torch.cuda.synchronize()
+        for tile in range(5):
+            r0, r1 = tiles.bounds[tile]
+            for key in ("val", "std"):
+                assert torch.equal(tiles.plans[tile].outputs[key], whole[key][r0:r1]), (row_elems, tile, key)

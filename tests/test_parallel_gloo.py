@@ -201,3 +201,21 @@ def test_shared_host_image_single_process():
     assert not os.path.exists(os.path.join(parallel.SharedHostImage.DIR, s.name))
     s.close()
     s.close()
+
+
+def test_tiles_of_an_odd_width_image_start_at_even_element_offsets():
+    """W * C odd (e.g. 333 x 3): the streaming kernels read element pairs, so a tile's first element must sit an even number of elements
+    into its input buffer. With row_elems given, tiles start on even rows and take an even number of halo rows above - covering, disjoint,
+    the halo still at least floor(k / 2) rows on both sides."""
+    from camera_linearity_amd import parallel as P
+    for height, tiles, k, row_elems in ((1001, 8, 3, 999), (1001, 8, 5, 999), (64, 7, 7, 333), (10, 3, 3, 21), (1001, 8, 3, 1000), (5, 8, 3, 9)):
+        bounds = P.row_tile_bounds(height, tiles, row_elems)
+        assert bounds[0][0] == 0 and bounds[-1][1] == height and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+        for r0, r1 in bounds:
+            b0, b1 = P.halo_bounds(r0, r1, height, k, row_elems)
+            assert b0 <= max(0, r0 - k // 2) and b1 == min(height, r1 + k // 2) and b0 >= 0
+            if row_elems % 2 == 1:
+                assert r0 % 2 == 0 and ((r0 - b0) * row_elems) % 2 == 0, (height, tiles, k, r0, b0)
+    ts = P.RowTileSet(1001, 8, median_k=3, row_elems=999)
+    assert ts.input_rows(1) == (ts.bounds[1][0] - 2, ts.bounds[1][1] + 1)
+    assert P.RowTileSet(1001, 8, median_k=3).input_rows(1) == (124, 251)          # unchanged without row_elems
