@@ -500,8 +500,51 @@ def case_energy(rng):
     return desc
 
 
+def case_series(rng):
+    """The drop-in classes end to end on both backends: ImageSet(value=uint8 frame, std) x N -> ExposureSeries.process_HDR_image(ICRF,
+    ICRF_diff, dark_list, flat_list) with the reference's dark-frame rule (exact-exposure dark, else the next longer one scaled by t / t_dark,
+    only for t >= DARK_THRESHOLD), hot-pixel medians, flat-field ROI means - and process_linearity on the same series. uint8 stacks: bit-exact."""
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    n = int(rng.integers(2, 9))
+    h, w = int(rng.integers(6, 40)), int(rng.integers(6, 50))
+    t = np.sort(rng.choice(np.array([0.004, 0.008, 0.016, 0.032, 0.064, 0.128, 0.256, 0.512, 1.024]), size=n, replace=False))
+    frames = [rng.integers(0, 256, (h, w, 3)).astype(np.uint8) for _ in range(n)]
+    with_std = bool(rng.random() < 0.7)
+    stds = [0.004 * (1 + rng.random((h, w, 3))) for _ in range(n)] if with_std else [None] * n
+    g, d = icrf_tables(rng, 3)
+    feats = lambda e, subj="s": {"illumination": "bf", "magnification": "5x", "exposure": float(e), "subject": subj}   # noqa: E731
+    dark_t = sorted(set(float(x) for x in rng.choice(np.array([0.016, 0.032, 0.064, 0.3, 2.0]), size=int(rng.integers(0, 4)), replace=False)))
+    darks = []
+    for e in dark_t:
+        dm = rng.integers(0, 12, (h, w, 3)).astype(np.uint8)
+        dm[rng.random(dm.shape) < rng.choice([0.003, 0.03])] = int(rng.choice([60, 140, 250]))
+        darks.append(dm)
+    use_flat = bool(with_std and rng.random() < 0.5)
+    flat = rng.integers(120, 250, (h, w, 3)).astype(np.uint8)
+    flat_std = 0.002 * (1 + rng.random((h, w, 3)))
+    settings.configure(DARK_THRESHOLD=float(rng.choice([0.01, 0.05, 0.2])), MEDIAN_FILTER_KERNEL_SIZE=int(rng.choice([3, 5])),
+                       FF_MID_PERCENTAGE=float(rng.choice([0.2, 0.5, 1.0])), IM_SIZE_X=None, IM_SIZE_Y=None)
+    desc = f"series n={n} {h}x{w}x3 std={with_std} darks={dark_t} flat={use_flat} thr={settings.DARK_THRESHOLD} k={settings.MEDIAN_FILTER_KERNEL_SIZE}"
+    out = []
+    for cupy in (GPU, False):
+        conv = (lambda a: None if a is None else D(a)) if cupy else (lambda a: None if a is None else a.copy())
+        sets = [ImageSet(value=conv(f), std=conv(s_), features=feats(e), use_cupy=cupy) for f, s_, e in zip(frames, stds, t)]
+        dl = [ImageSet(value=conv(dm), features=feats(e, "dark"), use_cupy=cupy) for dm, e in zip(darks, dark_t)] or None
+        fl = [ImageSet(value=conv(flat), std=conv(flat_std), features=feats(0.01, "flat"), use_cupy=cupy)] if use_flat else None
+        series = ExposureSeries(input_image_sets=sets)
+        series.process_HDR_image(g, d if with_std else None, dark_list=dl, flat_list=fl)
+        val, std_ = series.merged_image_set.host_arrays()
+        out.append((val, std_))
+    # bit-exact without a flat field; with one, the two ROI means (roi_mean: a reduction, summed in another order by the two builds) may
+    # differ in their last bit and scale every element by it
+    compare("series.val", out[0][0], out[1][0], 1e-14 if use_flat else None)
+    compare("series.std", out[0][1], out[1][1], 1e-13 if use_flat else None)
+    return desc
+
+
 CASES = [(case_merge, 5), (case_binary, 3), (case_unary, 1), (case_stats, 3), (case_pair, 2), (case_linearize, 2), (case_corrections, 2),
-         (case_hist_extract, 2), (case_linearity, 2), (case_welford, 2), (case_energy, 2)]
+         (case_hist_extract, 2), (case_linearity, 2), (case_welford, 2), (case_energy, 2), (case_series, 2)]
 weights = np.array([w for _, w in CASES], dtype=np.float64)
 weights /= weights.sum()
 counts = {fn.__name__: 0 for fn, _ in CASES}
