@@ -421,3 +421,63 @@ def test_bench_counter_records_go_stale_with_the_kernel_source(tmp_path, monkeyp
     blk = bench.valu_roofline("linearitystd", 2000.0, ("instructions_per_element_pair", 64e6))
     assert blk["frac"] == round(1.0e9 / 2000.0 / 1e3 / bench.VALU_PEAK_GINSTR, 4) and blk["instructions_per_element_pair"] == 1000.0
     assert bench.valu_roofline("welford", 100.0)["frac"] is None
+
+
+def test_hm_merge_survives_random_argument_structs():
+    """2 000 random hm_merge_args - wrong struct sizes, negative / huge / inconsistent geometry, NULL and misaligned pointers, too many or no
+    frames, both frame kinds at once, bad median sizes, NaN / zero / negative exposures - through hm_merge, hm_merge_describe and
+    hm_merge_algorithmic_bytes of the HIP library on a machine WITHOUT a GPU: every call returns (HM_OK for calls with nothing to do, a
+    negative HM_E* code otherwise), none crashes. Device pointers are fake addresses: validation must never dereference them."""
+    import random
+    from camera_linearity_amd import _native as nat
+    lib = nat.hip_lib
+    rng = random.Random(1)
+    seen = {}
+
+    def fake():
+        return 0x7f0000000000 + rng.randrange(0, 1 << 20) * 16 + rng.choice([0, 0, 0, 1, 3, 8])
+    for _ in range(2000):
+        a = nat.MergeArgs()
+        a.struct_size = rng.choice([C.sizeof(nat.MergeArgs)] * 6 + [264, 280, 0, 100, 1024])
+        n = rng.choice([1, 2, 7, 15, 16, 17, 32, 33, 40, 0, -1, 1000])
+        a.n_frames, a.channels = n, rng.choice([3, 3, 3, 1, 2, 4, 0, 5, -2])
+        a.variant = rng.choice([0, 0, 0, -1, -2, -5, 1120, 7300, 99999, -100])
+        H, W = rng.choice([0, 1, 5, 64, 4096, -3, 70000]), rng.choice([0, 1, 7, 64, 4096, -1, 1 << 20])
+        a.height, a.width = H, W
+        a.row0 = rng.choice([0, 0, 1, H // 2 if H > 0 else 0, -1, H + 5])
+        a.rows = rng.choice([H, max(H, 0) // 2, 0, -1, H + 1])
+        a.buf_row0 = rng.choice([0, 0, a.row0, a.row0 - 1, -2])
+        a.buf_rows = rng.choice([H, a.rows, a.rows + 2, 0, -1])
+        nn = max(1, min(abs(n), 64))
+        ptrs = (C.c_void_p * nn)(*[fake() if rng.random() < 0.9 else None for _ in range(nn)])
+        kind = rng.choice(["u8", "f64", "none", "both"])
+        if kind in ("u8", "both"):
+            a.frames_u8 = C.cast(ptrs, C.POINTER(C.c_void_p))
+        if kind in ("f64", "both"):
+            a.frames_f64 = C.cast(ptrs, C.POINTER(C.c_void_p))
+        if rng.random() < 0.5:
+            a.stds = C.cast(ptrs, C.POINTER(C.c_void_p))
+        exp = (C.c_double * nn)(*[rng.choice([1e-3, 1.0, 0.0, -1.0, float("nan"), float("inf"), 1e-310]) for _ in range(nn)])
+        if rng.random() < 0.9:
+            a.exposures = C.cast(exp, C.POINTER(C.c_double))
+        for f in ("icrf", "icrf_diff", "w_lut", "dw_lut", "flat_u8", "flat_f64", "flat_std", "out_val", "out_std", "out_sum_w", "hot_workspace",
+                  "frames_workspace"):
+            if rng.random() < 0.6:
+                setattr(a, f, fake())
+        keep = [ptrs, exp]
+        if rng.random() < 0.3:
+            a.darks_u8 = C.cast(ptrs, C.POINTER(C.c_void_p))
+            dm = (C.c_int32 * nn)(*[rng.choice([1, 100, 256, 0, -5, 300]) for _ in range(nn)])
+            keep.append(dm)
+            if rng.random() < 0.8:
+                a.dark_min_dn = C.cast(dm, C.POINTER(C.c_int32))
+            a.median_k = rng.choice([3, 5, 7, 1, 2, 4, 9, 0, -3])
+        a.hot_workspace_bytes = rng.choice([0, 16, 1 << 20, 0xFFFFFFFF])
+        a.frames_workspace_bytes = rng.choice([0, 16, 1 << 30])
+        rc = lib.hm_merge(C.byref(a), None)
+        assert rc <= 0
+        seen[rc] = seen.get(rc, 0) + 1
+        buf = C.create_string_buffer(256)
+        assert lib.hm_merge_describe(C.byref(a), buf, 256) <= 0
+        lib.hm_merge_algorithmic_bytes(C.byref(a))
+    assert seen.get(nat.HM_EINVAL, 0) > 1000 and len(seen) >= 3, seen
