@@ -6,6 +6,7 @@
 // Streaming, HBM-bound; the statistics are ONE deterministic reduction pass (per-thread Welford states combined with Chan's
 // formula by wave shuffles + LDS, then one workgroup), NaNs ignored exactly as np.nansum / np.nanmean / np.nanstd do.
 #include "hm_common.h"
+#include <initializer_list>
 #include <algorithm>
 
 namespace hm {
@@ -1614,6 +1615,16 @@ __global__ __launch_bounds__(256) void k_axis_final2_tree(const double* __restri
     if (threadIdx.x == 0) axis_finish_store(mom_load(tree[0]), f.weighted != 0, j, out_mean, out_std, out_err);
 }
 
+// the element count of a dense block of the given extents, or -1 when an extent is < 1 or the product does not fit (absurd arguments must
+// come back as HM_EINVAL / 0, not as an integer overflow inside the launch arithmetic)
+static int64_t dense_elems(std::initializer_list<int64_t> dims) {
+    int64_t n = 1;
+    for (int64_t d : dims) {
+        if (d < 1 || __builtin_mul_overflow(n, d, &n) || n > (int64_t{1} << 48)) return -1;
+    }
+    return n;
+}
+
 struct AxisPlan { bool row; int KS; };
 static AxisPlan axis_plan(int64_t outer, int64_t A, int64_t inner) {
     AxisPlan p;
@@ -1698,7 +1709,7 @@ static bool fill_bcast(Bcast2K& b, int ndim, const int64_t* shape, const int64_t
 }  // namespace hm
 
 extern "C" size_t hm_axis_statistics_workspace_bytes(int64_t outer, int64_t axis_len, int64_t inner) {
-    if (outer < 1 || axis_len < 1 || inner < 1) return 0;
+    if (hm::dense_elems({outer, axis_len, inner}) < 0) return 0;
     const hm::AxisPlan p = hm::axis_plan(outer, axis_len, inner);
     return p.KS > 1 ? static_cast<size_t>(p.KS) * static_cast<size_t>(outer * inner) * hm::kMomVals * sizeof(double) : 0;
 }
@@ -1725,7 +1736,7 @@ static void launch_axis_stage1(const double* val, const double* std, int64_t out
 extern "C" int hm_axis_statistics(const double* val, const double* std, int64_t outer, int64_t axis_len, int64_t inner,
                                   double* out_mean, double* out_std, double* out_err, void* workspace, void* stream) {
     using namespace hm;
-    if (outer < 1 || axis_len < 1 || inner < 1 || !val || !out_mean || !out_std) return HM_EINVAL;
+    if (dense_elems({outer, axis_len, inner}) < 0 || !val || !out_mean || !out_std) return HM_EINVAL;
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
     const AxisPlan p = axis_plan(outer, axis_len, inner);
     if (p.KS > 1 && !workspace) return HM_EINVAL;
@@ -1761,7 +1772,7 @@ static Axis2Plan axis2_plan(int64_t outer, int64_t a1, int64_t mid, int64_t a2, 
 }  // namespace hm
 
 extern "C" size_t hm_axis_statistics2_workspace_bytes(int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner) {
-    if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1) return 0;
+    if (hm::dense_elems({outer, a1, mid, a2, inner}) < 0) return 0;
     const hm::Axis2Plan q = hm::axis2_plan(outer, a1, mid, a2, inner);
     return static_cast<size_t>(q.p.KS) * static_cast<size_t>(q.f.n_out1) * hm::kMomVals * sizeof(double);
 }
@@ -1769,7 +1780,7 @@ extern "C" size_t hm_axis_statistics2_workspace_bytes(int64_t outer, int64_t a1,
 extern "C" int hm_axis_statistics2(const double* val, const double* std, int64_t outer, int64_t a1, int64_t mid, int64_t a2, int64_t inner,
                                    double* out_mean, double* out_std, double* out_err, void* workspace, void* stream) {
     using namespace hm;
-    if (outer < 1 || a1 < 1 || mid < 1 || a2 < 1 || inner < 1 || !val || !out_mean || !out_std || !workspace) return HM_EINVAL;
+    if (dense_elems({outer, a1, mid, a2, inner}) < 0 || !val || !out_mean || !out_std || !workspace) return HM_EINVAL;
     if (!aligned(val, 8) || (std && !aligned(std, 8))) return HM_EALIGN;
     Axis2Plan q = axis2_plan(outer, a1, mid, a2, inner);
     q.f.weighted = std ? 1 : 0;

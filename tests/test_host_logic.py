@@ -481,3 +481,62 @@ def test_hm_merge_survives_random_argument_structs():
         assert lib.hm_merge_describe(C.byref(a), buf, 256) <= 0
         lib.hm_merge_algorithmic_bytes(C.byref(a))
     assert seen.get(nat.HM_EINVAL, 0) > 1000 and len(seen) >= 3, seen
+
+
+def test_every_entry_point_survives_random_arguments():
+    """8 000 calls of random entry points of the HIP library with random scalars (negative, zero, 2^31 + 7, 2^40, 2^62 element counts; channel
+    counts 0..1000; NaN / inf parameters), fake or NULL device pointers and valid host arrays, on a machine WITHOUT a GPU: every int-returning
+    call returns <= 0 (HM_OK only where there is nothing to do, HM_ELAUNCH where valid arguments meet no device) and nothing crashes - no
+    integer overflow in launch arithmetic (found by this test: hm_axis_statistics_workspace_bytes(12, 2^31 + 7, 2^62) divided by zero),
+    no dereference of a device pointer on the host. Host arrays are 4096 entries long and counts that index them stay below that."""
+    import random
+    from camera_linearity_amd import _native as nat
+    lib = nat.hip_lib
+    rng = random.Random(3)
+    skip = {"hm_version", "hm_strerror", "hm_device_info", "hm_debug_clock_probe", "hm_debug_copy_probe", "hm_debug_stride_probe",
+            "hm_gaussian_weight_lut_host", "hm_merge", "hm_merge_algorithmic_bytes", "hm_merge_describe", "hm_tiff_lzw_decode", "hm_tiff_packbits_decode"}
+
+    def fake():
+        return 0x7f0000000000 + rng.randrange(0, 1 << 20) * 16 + rng.choice([0, 0, 0, 1, 4, 8])
+    keep = []
+
+    def gen(t):
+        if t is C.c_void_p:
+            return fake() if rng.random() < 0.85 else None
+        if t is C.c_int64:
+            return rng.choice([-1, 0, 1, 2, 3, 5, 12, 64, 1000, 4096, 1 << 20, (1 << 31) + 7, 1 << 40, 1 << 62])
+        if t is C.c_int:
+            return rng.choice([-1, 0, 1, 2, 3, 4, 5, 7, 8, 9, 16, 32, 33, 255, 256, 1000])
+        if t is C.c_double:
+            return rng.choice([0.0, 1.0, -1.0, 0.5, 2.2, 1e-310, float("nan"), float("inf")])
+        if isinstance(t, type) and issubclass(t, C._Pointer):
+            if rng.random() < 0.1:
+                return None
+            et = t._type_
+            if et is C.c_void_p:
+                arr = (C.c_void_p * 4096)(*[fake() if rng.random() < 0.9 else None for _ in range(4096)])
+            elif et is C.c_double:
+                arr = (C.c_double * 4096)(*[rng.choice([1e-3, 1.0, 0.0, -1.0, 2.0]) for _ in range(4096)])
+            elif et is C.c_int32:
+                arr = (C.c_int32 * 4096)(*[rng.choice([0, 1, 2, 5, -1, 40]) for _ in range(4096)])
+            elif et is C.c_int64:
+                arr = (C.c_int64 * 4096)(*[rng.choice([0, 1, 2, 3, 7, -1, 1 << 33]) for _ in range(4096)])
+            else:
+                return None
+            keep.append(arr)
+            return C.cast(arr, t)
+        raise TypeError(t)
+    names = sorted(n for n in nat._SIGNATURES if n not in skip)
+    codes = set()
+    for _ in range(8000):
+        name = rng.choice(names)
+        res, argt = nat._SIGNATURES[name]
+        a = [gen(t) for t in argt]
+        if name == "hm_pairs_statistics":                  # lower / upper are HOST arrays of C doubles (typed void* in the table)
+            a[9], a[10] = gen(C.POINTER(C.c_double)), gen(C.POINTER(C.c_double))
+        del keep[:-16]
+        rc = getattr(lib, name)(*a)
+        if res is C.c_int:
+            assert rc <= 0, (name, rc)
+            codes.add(rc)
+    assert nat.HM_EINVAL in codes and nat.HM_ELAUNCH in codes
