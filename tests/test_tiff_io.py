@@ -191,3 +191,43 @@ def test_truncated_and_garbage_directories(tmp_path):
     p.write_bytes(bytes(bad))
     with pytest.raises(ValueError):
         T.read_tiff(p)
+
+
+def test_decoders_and_reader_survive_random_corruption(tmp_path):
+    """The strip decoders (C, host side of libhdrmerge.so) on 10 000 random byte strings with random output capacities, and imread on 3 000
+    randomly corrupted or truncated copies of an 8-bit and a float64 TIFF: a decoder never writes past its capacity, a damaged file is either
+    read or refused with TiffError / NotImplementedError - nothing crashes, no other exception type escapes."""
+    import ctypes as C
+    import random
+    from camera_linearity_amd import _native as nat
+    lib = nat.hip_lib
+    rng = random.Random(5)
+    for _ in range(10000):
+        n = rng.choice([0, 1, 2, 3, 8, 64, 300, 5000])
+        src = bytes(rng.getrandbits(8) for _ in range(n)) if rng.random() < 0.7 else bytes([rng.choice([0x80, 0x00, 0xff, 0x01])] * n)
+        cap = rng.choice([0, 1, 7, 64, 1000, 70000])
+        dst = (C.c_uint8 * (max(cap, 1) + 16))()
+        guard = bytes(dst[max(cap, 1):])
+        for fn in (lib.hm_tiff_lzw_decode, lib.hm_tiff_packbits_decode):
+            assert fn(src, len(src), dst, cap) <= cap
+        assert bytes(dst[max(cap, 1):]) == guard                       # nothing beyond the capacity was touched
+    img = np.random.default_rng(0).integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    f64 = np.random.default_rng(1).random((20, 31, 3))
+    T.imwrite(tmp_path / "a.tif", img)
+    T.imwrite(tmp_path / "b.tif", f64)
+    outcomes = set()
+    for name in ("a.tif", "b.tif"):
+        raw = bytearray((tmp_path / name).read_bytes())
+        for _ in range(1500):
+            b = bytearray(raw)
+            for _k in range(rng.choice([1, 1, 2, 5, 20])):
+                b[rng.randrange(0, min(len(b), 400) if rng.random() < 0.7 else len(b))] = rng.getrandbits(8)
+            if rng.random() < 0.2:
+                b = b[:rng.randrange(0, len(b))]
+            (tmp_path / "c.tif").write_bytes(bytes(b))
+            try:
+                T.imread(tmp_path / "c.tif", T.IMREAD_UNCHANGED)
+                outcomes.add("read")
+            except (T.TiffError, NotImplementedError) as e:
+                outcomes.add(type(e).__name__)
+    assert {"read", "TiffError"} <= outcomes
