@@ -12,6 +12,9 @@
 // the TIFF strip decoders (host code already, in libhdrmerge.so) and the hm_debug_* probes.
 #include "hdrmerge.h"
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -334,39 +337,115 @@ int hm_merge_describe(const hm_merge_args* g, char* buf, int buf_len) {
 
 // exposure_series.py:340-394 per output element, the operation sequence of merge_one_element() (hm_merge.hip): S in frame order;
 // 1/S and 1/S**2 once; numerator and variance accumulated with fma in frame order; acc / S last; flat field last.
-int hm_merge(const hm_merge_args* g_in, void*) {
-    hm_merge_args full; bool hot = false;
-    const int rc = merge_check(g_in, full, hot);
-    if (rc != HM_OK) return rc;
-    const hm_merge_args* g = &full;
-    if (g->rows == 0) return HM_OK;
+}  // extern "C" (templates below)
+
+// One instantiation per (float64 frames, dark maps, std) combination: the per-element loop carries no run-time mode tests, and the row / column
+// of an element are only worked out where a median needs them. Same operations in the same order in every instantiation.
+template <bool F64IN, bool HOT, bool STD>
+static void merge_elements(const hm_merge_args* g, const double* inv_t, int k) {
     const int N = g->n_frames, C = g->channels;
-    const bool f64in = g->frames_f64 != nullptr, with_std = g->stds != nullptr && g->out_val != nullptr;
     const bool flat = g->flat_u8 || g->flat_f64;
     const int64_t W = g->width, wc = W * C, E = g->rows * wc;
     const int64_t in_off = (g->row0 - g->buf_row0) * wc;
-    std::vector<double> inv_t(static_cast<size_t>(N));
-    for (int i = 0; i < N; ++i) inv_t[static_cast<size_t>(i)] = 1.0 / g->exposures[i];
-    const int k = hot ? g->median_k : 3;
+    std::vector<double> wg_store;
+    if (!F64IN && !STD && g->out_val) {
+        wg_store.resize(static_cast<size_t>(256) * C);
+        for (int q = 0; q < 256 * C; ++q) wg_store[static_cast<size_t>(q)] = g->w_lut[q / C] * g->icrf[q];
+    }
+    const double* const wg_tab = wg_store.data();
 #pragma omp parallel
     {
         std::vector<double> vv(static_cast<size_t>(N)), ss(static_cast<size_t>(N));
         std::vector<uint32_t> dd(static_cast<size_t>(N));
-#pragma omp for schedule(static)
-        for (int64_t e = 0; e < E; ++e) {
+        double* const v = vv.data(); double* const sdv = ss.data(); uint32_t* const dn = dd.data();
+        // this thread's contiguous range of elements; the channel index runs along with e (a 64-bit remainder per element cost as much as
+        // the rest of a val-only element)
+        int64_t lo = 0, hi = E;
+#ifdef _OPENMP
+        {
+            const int64_t nt = omp_get_num_threads(), tid = omp_get_thread_num();
+            lo = E * tid / nt; hi = E * (tid + 1) / nt;
+        }
+#endif
+        if constexpr (!F64IN && !STD && !HOT) {
+            // val-only on DNs without dark maps (BASELINE config 2's arithmetic): four elements at a time - four independent sum / fma chains
+            // per frame instead of one (the chains are latency-bound: 7 dependent adds and 7 dependent fmas per element) - from the w g
+            // table; the same operations per element in the same order as the one-element loop below, which takes the tail.
+            if (wg_tab) {
+                constexpr int B = 4;
+                int cb[B];
+                for (; lo + B <= hi; lo += B) {
+                    const int64_t ei = in_off + lo;
+                    for (int j = 0; j < B; ++j) cb[j] = static_cast<int>((lo + j) % C);
+                    double S4[B], a4[B];
+                    for (int i = 0; i < N; ++i) {
+                        const uint8_t* p = g->frames_u8[i] + ei;
+                        const double it = inv_t[i];
+                        for (int j = 0; j < B; ++j) {
+                            const uint32_t d = p[j];
+                            const double w = g->w_lut[d], wg = wg_tab[d * C + cb[j]];
+                            S4[j] = i == 0 ? w : S4[j] + w;                          // exposure_series.py:340
+                            a4[j] = i == 0 ? wg * it : std::fma(wg, it, a4[j]);      // :388 numerator
+                        }
+                    }
+                    for (int j = 0; j < B; ++j) {
+                        const int64_t e = lo + j;
+                        if (g->out_sum_w) g->out_sum_w[e] = S4[j];
+                        double val = a4[j] / S4[j], none = 0.0;
+                        if (flat) {
+                            const double F = g->flat_u8 ? static_cast<double>(g->flat_u8[e]) / 255.0 : g->flat_f64[e];
+                            flat_field_math(F, 0.0, g->ff_mean[cb[j]], g->ff_std_mean[cb[j]], false, val, none);
+                        }
+                        g->out_val[e] = val;
+                    }
+                }
+            }
+        }
+        int c = static_cast<int>(lo % C) - 1;
+        for (int64_t e = lo; e < hi; ++e) {
             const int64_t ei = in_off + e;
-            const int c = static_cast<int>(e % C);
-            const int64_t row = g->row0 + e / wc, col = (e % wc) / C;
+            c = c + 1 == C ? 0 : c + 1;
             // the (filtered) frame values of this element
-            for (int i = 0; i < N; ++i) {
-                const bool h = hot && g->darks_u8[i] && static_cast<int>(g->darks_u8[i][ei]) >= g->dark_min_dn[i];   // measurand.py:545
-                if (f64in) vv[static_cast<size_t>(i)] = h ? median_at(g->frames_f64[i], g->height, W, C, g->buf_row0, row, col, c, k) : g->frames_f64[i][ei];
-                else dd[static_cast<size_t>(i)] = h ? median_at(g->frames_u8[i], g->height, W, C, g->buf_row0, row, col, c, k) : g->frames_u8[i][ei];
-                if (with_std) ss[static_cast<size_t>(i)] = h ? median_at(g->stds[i], g->height, W, C, g->buf_row0, row, col, c, k) : g->stds[i][ei];
+            if constexpr (HOT) {
+                const int64_t row = g->row0 + e / wc, col = (e % wc) / C;
+                for (int i = 0; i < N; ++i) {
+                    const bool h = g->darks_u8[i] && static_cast<int>(g->darks_u8[i][ei]) >= g->dark_min_dn[i];   // measurand.py:545
+                    if constexpr (F64IN) v[i] = h ? median_at(g->frames_f64[i], g->height, W, C, g->buf_row0, row, col, c, k) : g->frames_f64[i][ei];
+                    else dn[i] = h ? median_at(g->frames_u8[i], g->height, W, C, g->buf_row0, row, col, c, k) : g->frames_u8[i][ei];
+                    if constexpr (STD) sdv[i] = h ? median_at(g->stds[i], g->height, W, C, g->buf_row0, row, col, c, k) : g->stds[i][ei];
+                }
+            } else {
+                for (int i = 0; i < N; ++i) {
+                    if constexpr (F64IN) v[i] = g->frames_f64[i][ei]; else dn[i] = g->frames_u8[i][ei];
+                    if constexpr (STD) sdv[i] = g->stds[i][ei];
+                }
             }
             double S = 0.0;
+            if (!F64IN && !STD && wg_tab) {
+                // val-only on DNs: S and the numerator in ONE walk over the frames, the product w g from a table built once per call
+                // (wg_tab[dn C + c] = w_lut[dn] * icrf[dn C + c]: the same product of the same operands, the same bits)
+                double acc1 = 0.0;
+                const double* tab = wg_tab + c;
+                for (int i = 0; i < N; ++i) {
+                    const uint32_t d = dn[i];
+                    const double w = g->w_lut[d];
+                    S = i == 0 ? w : S + w;                                          // exposure_series.py:340
+                    acc1 = i == 0 ? tab[d * C] * inv_t[i] : std::fma(tab[d * C], inv_t[i], acc1);   // :388 numerator
+                }
+                if (g->out_sum_w) g->out_sum_w[e] = S;
+                if (!g->out_val) continue;
+                double val1 = acc1 / S;
+                if (flat) {
+                    double none = 0.0;
+                    const double F = g->flat_u8 ? static_cast<double>(g->flat_u8[e]) / 255.0 : g->flat_f64[e];
+                    flat_field_math(F, 0.0, g->ff_mean[c], g->ff_std_mean[c], false, val1, none);
+                }
+                g->out_val[e] = val1;
+                continue;
+            }
             for (int i = 0; i < N; ++i) {
-                const double w = f64in ? gauss_weight(vv[static_cast<size_t>(i)] - 0.5) : g->w_lut[dd[static_cast<size_t>(i)]];
+                double w;
+                if constexpr (F64IN) w = gauss_weight(v[i] - 0.5); else w = g->w_lut[dn[i]];
                 S = i == 0 ? w : S + w;                                              // exposure_series.py:340
             }
             if (g->out_sum_w) g->out_sum_w[e] = S;
@@ -375,36 +454,62 @@ int hm_merge(const hm_merge_args* g_in, void*) {
             double acc = 0.0, var = 0.0;
             for (int i = 0; i < N; ++i) {
                 double w, dw = 0.0; uint32_t idx;
-                if (f64in) {
-                    const double v = vv[static_cast<size_t>(i)], dv = v - 0.5;
+                if constexpr (F64IN) {
+                    const double dv = v[i] - 0.5;
                     w = gauss_weight(dv);
                     dw = (-60.0 * dv) * w;
-                    idx = lut_index(v);
+                    idx = lut_index(v[i]);
                 } else {
-                    idx = dd[static_cast<size_t>(i)];
+                    idx = dn[i];
                     w = g->w_lut[idx];
-                    if (with_std) dw = g->dw_lut[idx];
+                    if constexpr (STD) dw = g->dw_lut[idx];
                 }
                 const double gg = g->icrf[idx * C + c];
-                const double it = inv_t[static_cast<size_t>(i)];
+                const double it = inv_t[i];
                 const double wg = w * gg;
                 acc = i == 0 ? wg * it : std::fma(wg, it, acc);                     // :388 numerator
-                if (with_std) {
-                    const double dg = g->icrf_diff[idx * C + c] * ss[static_cast<size_t>(i)];            // measurand.py:512
+                if constexpr (STD) {
+                    const double dg = g->icrf_diff[idx * C + c] * sdv[i];                                // measurand.py:512
                     const double A = (dw * gg + w * dg) * invS - ((dw * w) * gg) * invS2;                // :389
                     const double term = (A * dg) * it;
                     var = i == 0 ? term * term : std::fma(term, term, var);
                 }
             }
             double val = acc / S;
-            double sd = with_std ? std::sqrt(var) : 0.0;                            // :394
+            double sd = STD ? std::sqrt(var) : 0.0;                                 // :394
             if (flat) {
                 const double F = g->flat_u8 ? static_cast<double>(g->flat_u8[e]) / 255.0 : g->flat_f64[e];
-                flat_field_math(F, with_std ? g->flat_std[e] : 0.0, g->ff_mean[c], g->ff_std_mean[c], with_std, val, sd);
+                flat_field_math(F, STD ? g->flat_std[e] : 0.0, g->ff_mean[c], g->ff_std_mean[c], STD, val, sd);
             }
             g->out_val[e] = val;
-            if (with_std) g->out_std[e] = sd;
+            if constexpr (STD) g->out_std[e] = sd;
         }
+    }
+}
+
+extern "C" {
+
+int hm_merge(const hm_merge_args* g_in, void*) {
+    hm_merge_args full; bool hot = false;
+    const int rc = merge_check(g_in, full, hot);
+    if (rc != HM_OK) return rc;
+    const hm_merge_args* g = &full;
+    if (g->rows == 0) return HM_OK;
+    const int N = g->n_frames;
+    const bool f64in = g->frames_f64 != nullptr, with_std = g->stds != nullptr && g->out_val != nullptr;
+    std::vector<double> inv_t(static_cast<size_t>(N));
+    for (int i = 0; i < N; ++i) inv_t[static_cast<size_t>(i)] = 1.0 / g->exposures[i];
+    const int k = hot ? g->median_k : 3;
+    const int mode = (f64in ? 4 : 0) | (hot ? 2 : 0) | (with_std ? 1 : 0);
+    switch (mode) {
+        case 0: merge_elements<false, false, false>(g, inv_t.data(), k); break;
+        case 1: merge_elements<false, false, true>(g, inv_t.data(), k); break;
+        case 2: merge_elements<false, true, false>(g, inv_t.data(), k); break;
+        case 3: merge_elements<false, true, true>(g, inv_t.data(), k); break;
+        case 4: merge_elements<true, false, false>(g, inv_t.data(), k); break;
+        case 5: merge_elements<true, false, true>(g, inv_t.data(), k); break;
+        case 6: merge_elements<true, true, false>(g, inv_t.data(), k); break;
+        default: merge_elements<true, true, true>(g, inv_t.data(), k); break;
     }
     return HM_OK;
 }
