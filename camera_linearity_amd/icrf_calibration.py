@@ -64,10 +64,10 @@ def _host(x):
 
 def _engine_for(stack: torch.Tensor):
     """The HIP library for a device-resident stack; the host build of the same ABI for a host stack (initialize_channel_image_stacks(...,
-    device="cpu")). The stack's placement decides, exactly as the reference picks NumPy or CuPy from the array it is handed
-    (`get_array_lib(values)`, modules/array_wrapper.py:37-50; modules/ICRF_calibration_exposure.py:89) - the caller's choice when it
-    built the stacks, never a fallback: a device stack never computes on the host, and the default device of
-    initialize_channel_image_stacks is the current GPU (it raises without one)."""
+    device="cpu")). The reference makes this choice once per calibration - `calibration(..., use_cupy)` switches the module's array
+    library (modules/ICRF_calibration_exposure.py:17, :317-319) and the stacks are created in it; here the choice is the `device` the
+    caller gives initialize_channel_image_stacks (default: the current GPU - it raises without one) and every later call follows the
+    stacks' placement. Never a fallback: a device stack never computes on the host."""
     if not isinstance(stack, torch.Tensor) or stack.is_cuda:        # (anything but a tensor: engine raises the TypeError)
         return engine
     from .measurand import _HOST_ENGINE
