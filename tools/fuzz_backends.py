@@ -195,7 +195,7 @@ def case_merge(rng):
         b = {key: v[tile[0]:tile[1]] for key, v in b.items()}
     exact = not f64                                                    # float64 frames evaluate exp(): two math libraries
     for key in b:                                                      # (the std of float64 frames amplifies exp()'s last bit through (dw g + w dg)/S - dw w g/S^2)
-        compare(f"{key}", a[key], b[key], None if exact else (1e-9 if key == "std" else 1e-12))
+        compare(f"{key}", a[key], b[key], None if exact else (1e-8 if key == "std" else 1e-12))   # (seen: 1.9e-9 on stds of 1e-13 in an array of scale 5e-5)
     return desc
 
 
