@@ -12,47 +12,75 @@
 // TIFF 6.0 LZW (Compression = 5): MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, code width
 // grows one code early ("early change", as libtiff writes). Returns the number of bytes produced, or HM_EINVAL
 // for a corrupt stream / HM_ESHAPE if dst_cap is too small.
+//
+// The string table holds no characters: every string a code stands for has ALREADY been written to the output, so an entry is
+// (position, length) into dst. The entry made after emitting string(old) and reading `code` is string(old) + first byte of string(code) -
+// and those are adjacent in the output: it is (position of old's emission, length(old) + 1). Emitting a code is then one forward copy
+// inside dst (the KwKwK case - a code that is defined by the very emission in progress - is the same copy overlapping itself by one
+// byte, as in LZ77). The first version walked a prefix chain backwards for every output byte (dependent loads): 135 MB/s on noise and
+// 540 MB/s on smooth images per thread.
 extern "C" int64_t hm_tiff_lzw_decode(const uint8_t* src, int64_t src_len, uint8_t* dst, int64_t dst_cap) {
     if (!src || !dst || src_len < 0 || dst_cap < 0) return HM_EINVAL;
     enum { kClear = 256, kEoi = 257, kFirst = 258, kMax = 4096 };
-    uint16_t prefix[kMax];
-    uint8_t suffix[kMax], first[kMax];
-    uint16_t length[kMax];
-    for (int i = 0; i < 256; ++i) { prefix[i] = 0; suffix[i] = static_cast<uint8_t>(i); first[i] = static_cast<uint8_t>(i); length[i] = 1; }
+    if (dst_cap > 0xFFFFFFFFll) dst_cap = 0xFFFFFFFFll;           // 32-bit positions (24 KB of tables, L1-resident); a strip is far smaller
+    uint32_t pos[kMax];
+    uint16_t len[kMax];
     int nbits = 9, next = kFirst, old = -1;
+    uint32_t old_pos = 0, old_len = 0;
     uint64_t acc = 0;
     int have = 0;
     int64_t ip = 0, op = 0;
     for (;;) {
-        while (have < nbits && ip < src_len) { acc = (acc << 8) | src[ip++]; have += 8; }
-        if (have < nbits) break;                                   // ran out of input without EOI: accept what we have
+        if (have < nbits) {                                        // refill: four bytes at a time while the input lasts
+            if (ip + 4 <= src_len) {
+                acc = (acc << 32) | (static_cast<uint32_t>(src[ip]) << 24 | static_cast<uint32_t>(src[ip + 1]) << 16 |
+                                     static_cast<uint32_t>(src[ip + 2]) << 8 | src[ip + 3]);
+                ip += 4; have += 32;
+            } else {
+                while (have < nbits && ip < src_len) { acc = (acc << 8) | src[ip++]; have += 8; }
+                if (have < nbits) break;                           // ran out of input without EOI: accept what we have
+            }
+        }
         const int code = static_cast<int>((acc >> (have - nbits)) & ((1u << nbits) - 1u));
         have -= nbits;
         if (code == kEoi) break;
         if (code == kClear) { nbits = 9; next = kFirst; old = -1; continue; }
-        int emit;                                                  // the table entry to write out
+        uint32_t from = 0, n = 1;                                  // the string of `code`: n bytes at dst + from (codes >= 258)
         if (old < 0) {
             if (code >= 256) return HM_EINVAL;
-            emit = code;
         } else {
             if (code > next || next >= kMax + 1) return HM_EINVAL;
-            if (next < kMax) {                                     // new entry: string(old) + first char of the emitted string
-                prefix[next] = static_cast<uint16_t>(old);
-                first[next] = first[old];
-                length[next] = static_cast<uint16_t>(length[old] + 1);
-                suffix[next] = code < next ? first[code] : first[old];
-                ++next;
-            } else if (code >= kMax) {
-                return HM_EINVAL;
+            if (code >= kFirst) {
+                if (code >= kMax) return HM_EINVAL;
+                if (code < next) { from = pos[code]; n = len[code]; }
+                else { from = old_pos; n = old_len + 1; }          // code == next: string(old) + its own first byte (overlaps by one)
             }
-            emit = code;
+            if (next < kMax) {                                     // new entry: string(old) + first byte of the string being emitted now
+                pos[next] = old_pos;
+                len[next] = static_cast<uint16_t>(old_len + 1);
+                ++next;
+            }
         }
-        const int len = length[emit];
-        if (op + len > dst_cap) return HM_ESHAPE;
-        uint8_t* p = dst + op + len;
-        for (int c = emit, k = 0; k < len; ++k) { *--p = suffix[c]; c = prefix[c]; }
-        op += len;
-        old = code;
+        if (op + n > dst_cap) return HM_ESHAPE;
+        uint8_t* p = dst + op;
+        if (code < 256) {
+            *p = static_cast<uint8_t>(code);
+        } else {
+            const uint8_t* q = dst + from;
+            if (n <= 16 && from + n <= op && op + 16 <= dst_cap) {
+                // short strings (the common case on noisy images): sixteen bytes loaded, then stored - the bytes past n are overwritten by the
+                // next emissions (reads stay inside dst: from < op and op + 16 <= dst_cap)
+                uint64_t lo, hi;
+                memcpy(&lo, q, 8); memcpy(&hi, q + 8, 8);
+                memcpy(p, &lo, 8); memcpy(p + 8, &hi, 8);
+            } else if (from + n <= op) {
+                memcpy(p, q, n);
+            } else {
+                for (uint32_t k = 0; k < n; ++k) p[k] = q[k];      // forward: the one-byte overlap (KwKwK) reads what this loop wrote
+            }
+        }
+        old = code; old_pos = static_cast<uint32_t>(op); old_len = n;
+        op += n;
         if (next + 1 >= (1 << nbits) && nbits < 12) ++nbits;       // early change
     }
     return op;
