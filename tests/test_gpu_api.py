@@ -298,6 +298,7 @@ def test_c_abi_example_from_plain_c(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C ABI merge OK" in r.stdout
+    assert "hipGraph replay of the captured hm_merge: identical bits" in r.stdout      # hipStreamBeginCapture ... hm_merge ... hipGraphLaunch from plain C
 
 
 def test_out_of_scope_methods_fail_loudly(M):
