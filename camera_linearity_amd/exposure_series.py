@@ -39,6 +39,17 @@ def icrf_derivative(ICRF, bits: int = None):
     return out
 
 
+def _roi_means(flat_set, eng, t: torch.Tensor, bounds, which: str) -> np.ndarray:
+    """Per-channel ROI means of a flat field (modules/measurand.py:570-583) as host numbers - remembered on the flat's ImageSet: one flat
+    serves many exposure series, and each evaluation is a small reduction kernel plus a device-to-host copy that the merge would wait
+    for. The key holds the tensor's identity and version (an in-place edit or a new image computes again)."""
+    cache = flat_set.__dict__.setdefault("_roi_mean_cache", {})       # which ("val" / "std") -> (key, means): one image and one ROI each
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.device), tuple(bounds))
+    if cache.get(which, (None, None))[0] != key:
+        cache[which] = (key, eng.roi_mean(t, *bounds).cpu().numpy())
+    return cache[which][1]
+
+
 def read_ICRF_file(file_path, return_derivative: bool = True):
     """modules/general_functions.py:254-277 with the intended return value (the derivative, not the ICRF twice)."""
     icrf = np.loadtxt(file_path, dtype=float)
@@ -254,14 +265,14 @@ class ExposureSeries(object):
             size_x = gs.IM_SIZE_X or fval.shape[0]
             size_y = gs.IM_SIZE_Y or fval.shape[1]
             x0, x1, y0, y1 = engine.flat_roi_bounds(size_x, size_y, gs.FF_MID_PERCENTAGE)
-            kw.update(flat=fval, ff_mean=eng.roi_mean(fval, x0, x1, y0, y1).cpu().numpy())
+            kw.update(flat=fval, ff_mean=_roi_means(flat_set, eng, fval, (x0, x1, y0, y1), "val"))
             if use_std:
                 if fm._std is None:
                     flat_set.load_std_image()
                 if fm._std is None:
                     raise ValueError("flat field needs a std image to propagate uncertainty")
                 fstd = fm._std.to(dev)
-                kw.update(flat_std=fstd, ff_std_mean=eng.roi_mean(fstd, x0, x1, y0, y1).cpu().numpy())
+                kw.update(flat_std=fstd, ff_std_mean=_roi_means(flat_set, eng, fstd, (x0, x1, y0, y1), "std"))
         exposures = [s.features["exposure"] for s in sets]
         out = eng.merge(frames, exposures, ICRF, ICRF_diff if use_std else None, stds, darks=darks, dark_min=mins,
                         median_k=gs.MEDIAN_FILTER_KERNEL_SIZE, **kw)

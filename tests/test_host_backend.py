@@ -380,3 +380,35 @@ def test_host_calibration_recovers_response():
     assert e_true < e0 / 10
     icrf, e, n_it = cal.solve_channel(mean_icrf, pca, stacks[0], None, tt, -1.0, 1.0, seed=7, max_iterations=30, vectorized=True)
     assert icrf.shape == (256,) and e < e0 / 10, (e, e0, e_true)
+
+
+def test_flat_roi_means_are_computed_once_per_flat(golden):
+    """One flat field serves many exposure series: its ROI means (a reduction + a copy to the host) are remembered on the flat's ImageSet and
+    computed again only when the flat image or the ROI changes."""
+    from camera_linearity_amd import _native as nat, settings as gs
+    from camera_linearity_amd.exposure_series import ExposureSeries
+    from camera_linearity_amd.image_set import ImageSet
+    g = golden("merge_full")
+    old = (gs.DARK_THRESHOLD, gs.FF_MID_PERCENTAGE, gs.MEDIAN_FILTER_KERNEL_SIZE)
+    gs.configure(DARK_THRESHOLD=float(g["dark_threshold"]), FF_MID_PERCENTAGE=float(g["ff_mid"]), MEDIAN_FILTER_KERNEL_SIZE=int(g["median_k"]))
+    try:
+        flat = ImageSet(value=g["flat"], std=g["flat_std"], features=dict(_features(0.01), subject="flat"))
+        calls = nat.host_lib().calls
+
+        def run():
+            sets = [ImageSet(value=g["frames"][i], std=g["stds"][i], features=_features(t)) for i, t in enumerate(g["exposures"])]
+            series = ExposureSeries(input_image_sets=sets)
+            series.process_HDR_image(g["icrf"], g["icrf_diff"], flat_list=[flat])
+            return series.merged_image_set.host_arrays()
+        before = calls["hm_roi_mean_u8"] + calls["hm_roi_mean_f64"]
+        v1, s1 = run()
+        mid = calls["hm_roi_mean_u8"] + calls["hm_roi_mean_f64"]
+        v2, s2 = run()
+        after = calls["hm_roi_mean_u8"] + calls["hm_roi_mean_f64"]
+        assert mid - before == 2 and after == mid                      # value and std means once; the second series reuses them
+        assert np.array_equal(v1, v2) and np.array_equal(s1, s2)
+        gs.configure(FF_MID_PERCENTAGE=0.5)                            # another ROI: computed again
+        run()
+        assert calls["hm_roi_mean_u8"] + calls["hm_roi_mean_f64"] == after + 2
+    finally:
+        gs.configure(DARK_THRESHOLD=old[0], FF_MID_PERCENTAGE=old[1], MEDIAN_FILTER_KERNEL_SIZE=old[2])
