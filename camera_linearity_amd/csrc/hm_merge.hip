@@ -13,7 +13,7 @@
 //
 // Kernels (hm_merge dispatches; all share one operation sequence per output element, so a result does not depend on
 // which kernel or tiling produced it):
-//   merge_u8_val3                       uint8 frames, C == 3, N <= 16 (compile-time), val-only, no extras: the bench kernel (config 2).
+//   merge_u8_val3                       uint8 frames, C == 3, N <= 20 (compile-time), val-only, no extras: the bench kernel (config 2).
 //   merge_u8_fast / merge_u8_fast_std   the same frames with std, flat field or sum-of-weights output (config 3).
 //   merge_u8_loop / merge_u8_loop_std   uint8 frames, run-time N (17..32) and C (1..4): same decomposition, frames in chunks.
 //   merge_f64_val / merge_f64_std       float64 frames (64-bit mode): analytic weight, computed LUT index.
@@ -1560,6 +1560,7 @@ __global__ __launch_bounds__(256) void merge_u8_val3(const MergeK a) {
 // packed words in registers. No cross-group prefetch: the kernel stays under 64 VGPRs and relies on 8 waves/SIMD.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLoopChunk = 8;
+constexpr int kTemplatedN = 20;                    // frame counts with their own instantiation of the templated kernels (see hm_merge's dispatch)
 
 template <int C, bool STD, bool FLAT, bool SUMW>
 __device__ __forceinline__ void merge_u8_loop_body(const MergeK& a) {
@@ -2594,7 +2595,10 @@ extern "C" int hm_merge(const hm_merge_args* g_in, void* stream) {
     bool fast = g->out_val && E < (int64_t{1} << 32) && g->variant >= 0;
     const bool mono_val3 = use_val3_mono(k, with_std, f64in);
     const bool mono_std = use_fast_std_mono(k, with_std, f64in);
-    const bool loop_kernel = (f64in || N > 16 || C != 3) && !mono_val3 && !mono_std;         // run-time-N / any-C streaming kernel instead of the N <= 16 templates
+    // Templates up to kTemplatedN = 20 frames (round 4, late: 16 before). On 2048 x 4096 x 3 stacks the templated kernels beat the run-time-N
+    // kernel at N = 17 (val-only 115 against 130 us, with std 790 against 880 us) and N = 20 (132 against 150, 985 against 1 025 us) and lose from
+    // N = 24 (with std) / 32 (val-only) on, where their per-frame register arrays no longer fit (profiles/r04z_n32_templates_ab.log).
+    const bool loop_kernel = (f64in || N > kTemplatedN || C != 3) && !mono_val3 && !mono_std;   // run-time-N / any-C streaming kernel instead of the templates
     if (fast) {
         for (int i = 0; i < N && fast; ++i) {
             fast = f64in ? aligned(static_cast<const double*>(k.frame[i]) + k.in_off, 16)
@@ -2620,6 +2624,8 @@ extern "C" int hm_merge(const hm_merge_args* g_in, void* stream) {
 #define HM_CASE(n) case n: rc = launch_fast_nf<n>(kb, cfg, with_std, st); break;
                 HM_CASE(1) HM_CASE(2) HM_CASE(3) HM_CASE(4) HM_CASE(5) HM_CASE(6) HM_CASE(7) HM_CASE(8)
                 HM_CASE(9) HM_CASE(10) HM_CASE(11) HM_CASE(12) HM_CASE(13) HM_CASE(14) HM_CASE(15) HM_CASE(16)
+                HM_CASE(17) HM_CASE(18) HM_CASE(19) HM_CASE(20)
+                static_assert(kTemplatedN == 20, "one HM_CASE per templated frame count");
 #undef HM_CASE
                 default: rc = f64in ? launch_f64(kb, with_std, st) : launch_loop(kb, with_std, st); break;   // run-time frame count
             }

@@ -240,10 +240,11 @@ def test_hot_pixel_filter_burst_and_tail(eng, density, k):
 
 # ------------------------------------------------------------------ seeded stacks vs the oracle
 @pytest.mark.parametrize("n,h,w", [(1, 5, 7), (2, 16, 16), (7, 33, 29), (7, 64, 128), (15, 24, 40), (16, 9, 11),
-                                   (17, 8, 8), (32, 4, 6), (24, 40, 33), (32, 31, 50)])
+                                   (17, 8, 8), (32, 4, 6), (24, 40, 33), (32, 31, 50), (17, 64, 128), (18, 40, 33), (19, 31, 50), (20, 64, 128),
+                                   (21, 40, 33)])
 @pytest.mark.parametrize("with_std", [False, True])
 def test_merge_vs_oracle_sizes(eng, n, h, w, with_std):
-    """Covers the fast kernel (N <= 16, whole 256/512-element groups), its tail, the run-time-N kernel (N > 16) and
+    """Covers the fast kernel (N <= 20, whole 256/512-element groups), its tail, the run-time-N kernel (N > 20) and
     the generic kernel (tiny images, tails)."""
     frames, stds, t = orc.synthetic_stack(100 + n, n, h, w, with_std=with_std)
     icrf, diff = orc.synthetic_icrf()
@@ -397,11 +398,11 @@ def test_hot_pixel_queue_smallest_workspace(eng):
     assert torch.equal(plan.outputs["val"], old.outputs["val"]) and torch.equal(plan.outputs["std"], old.outputs["std"])
 
 
-@pytest.mark.parametrize("n", [7, 8, 17, 20, 32])          # (8 + std + flat + sum of weights: the instantiation that spilled 20 B/lane in round 3)
+@pytest.mark.parametrize("n", [7, 8, 17, 18, 19, 20, 21, 32])          # (8 + std + flat + sum of weights: the instantiation that spilled 20 B/lane in round 3)
 @pytest.mark.parametrize("with_std", [False, True])
 def test_generic_kernel_bit_identical_to_fast_kernel(eng, with_std, n):
-    """variant < 0 forces merge_generic; it must reproduce merge_u8_fast (N <= 16) and merge_u8_loop (run-time frame
-    count, 16 < N <= 32) bit for bit (shared operation sequence), including flat field and sum-of-weights output."""
+    """variant < 0 forces merge_generic; it must reproduce merge_u8_fast (N <= 20) and merge_u8_loop (run-time frame
+    count, 20 < N <= 32) bit for bit (shared operation sequence), including flat field and sum-of-weights output."""
     h, w = 96, 130
     frames, stds, t = orc.synthetic_stack(77, n, h, w, with_std=with_std)
     icrf, diff = orc.synthetic_icrf()

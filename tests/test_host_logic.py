@@ -296,7 +296,8 @@ def test_merge_dispatch_table():
     assert _describe(7, flat=True)[1] == "merge_u8_val3<N=7,U=2,PF=1,MAP=3,flat=1>"             # val-only with a uint8 flat field: the bench kernel's FLAT instantiation
     assert _describe(15, flat=True)[1] == "merge_u8_val3<N=15,U=2,PF=1,MAP=0,flat=1>"
     assert _describe(7, flat=True, sumw=True)[1] == "merge_u8_fast<N=7,U=2,flat=1,sum_w=1>"
-    assert _describe(17)[1] == "merge_u8_loop<C=3,flat=0,sum_w=0>(N=17)"
+    assert _describe(17)[1] == "merge_u8_val3<N=17,U=3,PF=0,MAP=0>" and _describe(20, std=True)[1] == "merge_u8_fast_std<N=20,U=1,flat=0,sum_w=0>"   # templated up to N = 20
+    assert _describe(21)[1] == "merge_u8_loop<C=3,flat=0,sum_w=0>(N=21)" and _describe(32, std=True)[1] == "merge_u8_loop_std<C=3,flat=0,sum_w=0>(N=32)"
     assert _describe(7, C=1)[1] == "merge_u8_val3<N=7,U=4,PF=1,MAP=3,C=1>"                  # monochrome val-only: the bench kernel with one table column
     assert _describe(7, C=1, flat=True)[1] == "merge_u8_val3<N=7,U=2,PF=1,MAP=3,flat=1,C=1>"
     assert _describe(7, C=1, std=True)[1] == "merge_u8_fast_std<N=7,U=1,flat=0,sum_w=0,C=1>"
