@@ -2102,7 +2102,10 @@ struct Val3Cfg { int u, pf, map; };
 // chain, two sets of gathered values, 158 VGPRs = 3 waves/SIMD at N = 7) are 2.0 us faster than MAP = 0 in three same-process A/B runs with
 // shared output buffers on two boxes (129.25 / 126.1 / 128.5 against 131.3 / 128.1 / 130.2 us, profiles/r03_ab_pipe_n7_box*.json) and make no
 // difference for N = 15 (<3, 0, 3> 105.1 against 105.2 us at 133 instead of 82 VGPRs; profiles/r03_ab_pipe_n15_box1.json), which keeps MAP = 0.
-constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 8 ? Val3Cfg{4, 1, 3} : Val3Cfg{3, 0, 0}; }
+// N = 8 takes three sub-units per wave instead of four: 73.0 against 77.9 us on 2048 x 4096 x 3 stacks (0.689 against 0.646; a sweep of every
+// frame count with a dip in tools/bench_n.py - 6, 8, 10, 16 - late in round 4: profiles/r04x_sweep8.log, r04x_sweep6_10_16.log; the others
+// are within 3 % of their best variant as they stand).
+constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 7 ? Val3Cfg{4, 1, 3} : n_frames == 8 ? Val3Cfg{3, 1, 3} : Val3Cfg{3, 0, 0}; }
 static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
     c = val3_default(n_frames);
     if (variant == 0) return true;

@@ -277,7 +277,7 @@ def test_merge_dispatch_table():
     run-time-N kernels, float64 frames to merge_f64_*, unaligned frames to merge_generic, dark maps add the fix-up pass."""
     from camera_linearity_amd import _native as nat
     assert _describe(7) == (0, "merge_u8_val3<N=7,U=4,PF=1,MAP=3>")
-    assert _describe(8)[1] == "merge_u8_val3<N=8,U=4,PF=1,MAP=3>"
+    assert _describe(8)[1] == "merge_u8_val3<N=8,U=3,PF=1,MAP=3>"             # (N = 8: three sub-units per wave, profiles/r04x_sweep8.log)
     assert _describe(15)[1] == "merge_u8_val3<N=15,U=3,PF=0,MAP=0>"
     assert _describe(7, H=4, W=8)[1] == "merge_generic<f64in=0,std=0>"                      # 96 elements: less than one group
     assert _describe(7, H=5, W=64)[1] == "merge_u8_val3<N=7,U=4,PF=1,MAP=3> + merge_generic<f64in=0,std=0>"   # 960 = 1 unit of 512 + tail
