@@ -2105,7 +2105,12 @@ struct Val3Cfg { int u, pf, map; };
 // N = 8 takes three sub-units per wave instead of four: 73.0 against 77.9 us on 2048 x 4096 x 3 stacks (0.689 against 0.646; a sweep of every
 // frame count with a dip in tools/bench_n.py - 6, 8, 10, 16 - late in round 4: profiles/r04x_sweep8.log, r04x_sweep6_10_16.log; the others
 // are within 3 % of their best variant as they stand).
-constexpr Val3Cfg val3_default(int n_frames) { return n_frames <= 7 ? Val3Cfg{4, 1, 3} : n_frames == 8 ? Val3Cfg{3, 1, 3} : Val3Cfg{3, 0, 0}; }
+// N = 9 and N = 10 take two sub-units (with / without the second register set): 78.8 against 81.2 us and 84.8 against 89.4 us
+// (profiles/r04x_sweep9_14.log); 11-14 are within 1 % of their best variant with the shape of N = 15.
+constexpr Val3Cfg val3_default(int n_frames) {
+    return n_frames <= 7 ? Val3Cfg{4, 1, 3} : n_frames == 8 ? Val3Cfg{3, 1, 3} : n_frames == 9 ? Val3Cfg{2, 1, 0} : n_frames == 10 ? Val3Cfg{2, 0, 0}
+                                                                                                                               : Val3Cfg{3, 0, 0};
+}
 static bool val3_variant(int variant, int n_frames, Val3Cfg& c) {
     c = val3_default(n_frames);
     if (variant == 0) return true;
