@@ -303,6 +303,7 @@ __device__ __forceinline__ double rcp_nr(double x);
 // pair kernels, which are FP64-VALU bound and fold two states per 8 element-pairs
 template <bool RCP = false>
 __device__ __forceinline__ void acc_fold(MomAcc& a) {
+    if (!a.haveK && a.S0 != 0.0) { a.K = a.S2; a.S2 = 0.0; }        // a lone parked element (weighted_first below): it is its own shift, d = 0
     if (!is_finite(a.S1)) {                                         // acc_add_pair let infinite terms in: their sum's class goes to M2, the block is not folded
         a.m.M2 += a.S1;
         a.K = 0.0; a.haveK = false;                                 // (K may be the clamped +-1e300 of an infinite first element: take a new one)
@@ -324,6 +325,27 @@ __device__ __forceinline__ void acc_fold(MomAcc& a) {
     a.S0 = 0.0; a.S1 = 0.0; a.S2 = 0.0;
 }
 
+// WEIGHTED statistics, the first elements of a lane (no shift yet): the shift must not be an element that barely counts. A relative
+// difference against y ~ 0 is huge AND has a huge std, i.e. a weight ~ 0: as the shift K of a block it makes every ordinary element
+// contribute w (v - K)^2 ~ 1e14 to S2, and M2 = S2 - S1^2 / S0 then carries eps x that - 2.8e-6 on a std in one case of
+// tools/fuzz_backends.py (seed 1760803113997506811: K = 1.4e6 with weight 4e-12 beside values of 0.05 with weight 54). So the first element
+// is PARKED - its weight in S0, its value in S2, nothing accumulated - and when the second arrives the heavier of the two becomes K and both
+// are accumulated about it (exactly: one of the two deviations is 0). Elements of weight 0 add nothing to the moments and are passed over.
+// Returns true when the element has been dealt with here. (acc_fold turns a parked element that stayed alone into a block of its own.)
+// Used by the HBM-bound kernels (acc_add: channel and axis statistics); the FP64-bound pair kernels keep the first element as the shift
+// (see acc_add_pair) and with it the limit on unthresholded heavy-tailed data described in DESIGN.md 4.4.
+__device__ __forceinline__ bool weighted_first(MomAcc& a, double v, double w) {
+    if (w == 0.0) return true;
+    if (a.S0 == 0.0) { a.S0 = w; a.S2 = v; return true; }          // park
+    const double vp = a.S2, wp = a.S0;
+    a.K = w > wp ? v : vp;
+    const double dp = vp - a.K, dn = v - a.K;
+    const double tp = wp * dp, tn = w * dn;
+    a.S0 = wp + w; a.S1 = tp + tn; a.S2 = fma(tn, dn, tp * dp);
+    a.haveK = true;
+    return true;
+}
+
 // one element: value v, weight w (already formed; 1 when unweighted), std s for the `error` sum; in_range = the element exists (tail lanes)
 __device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s, bool weighted, bool in_range) {
     bool use;
@@ -341,9 +363,10 @@ __device__ __forceinline__ void acc_add(MomAcc& a, double v, double w, double s,
         a.m.M2 += (in_range && !use && v == v) ? v : 0.0;
         w = 1.0;
     }
+    if (weighted && use && !a.haveK) { weighted_first(a, v, w); return; }   // (rare: a lane's first two elements; v is finite here - v w is)
     a.K = (!a.haveK && use) ? v : a.K;
-    a.haveK = a.haveK || (use && w != 0.0);                                 // an element of weight 0 (std = inf) has added nothing yet: the next one
-    const double we = use ? w : 0.0;                                        // re-takes K (K far from the weighted data costs sqrt(eps) |K - mean| on the std)
+    a.haveK = a.haveK || use;
+    const double we = use ? w : 0.0;
     const double d = use ? v - a.K : 0.0;
     const double t = we * d;
     a.S0 += we; a.S1 += t; a.S2 = fma(t, d, a.S2);
@@ -399,7 +422,7 @@ __device__ __forceinline__ void acc_add_pair(MomAcc& a, double v, double w, doub
             if constexpr (!LEAN) {
                 if (!a.haveK) {                       // (elements of weight 0 - std = inf - have added nothing: K is re-taken until one counts)
                     asm volatile("" ::: "memory");
-                    a.K = finite_shift(v);
+                    a.K = finite_shift(v);            // (weighted_first() here costs the std kernel 12 bytes of scratch and 11 %: 2 410 -> 2 670 us)
                     a.haveK = WEIGHTED ? (w != 0.0) : true;
                 }
             }

@@ -929,3 +929,27 @@ def test_statistics_zero_weight_first_element_and_no_spread(M):
         ref = orc.dimension_statistics(big, sb, 0)
     np.testing.assert_allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=1e-12)
     np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=1e-10, atol=1e-12)
+
+
+def test_weighted_statistics_with_a_negligible_outlier_first(M):
+    """Weighted statistics whose FIRST element per line is a huge value with a negligible weight (a relative difference against y ~ 0: 1.4e6 with
+    weight 4e-12 beside values of 0.05 with weight 54 - the case tools/fuzz_backends.py found): as the moments' shift it cost 2.8e-6 on the std;
+    the channel / axis statistics kernels now take the heavier of a lane's first two elements as the shift. Against the NumPy oracle at 1e-10."""
+    rng = np.random.default_rng(8)
+    n, c = 5000, 3
+    x = 0.05 * rng.normal(size=(n, c))
+    s = np.full((n, c), 1 / 54.0) * (1 + 0.1 * rng.random((n, c)))
+    x[0, :] = [1.4e6, -3.0e5, 8.0e4]                       # the first element of every column
+    s[0, :] = [2.6e11, 1.0e10, 5.0e9]
+    x[1234, 1] = 2.0e6; s[1234, 1] = 1.0e12               # and one in the middle of a column
+    with np.errstate(all="ignore"):
+        ref = orc.dimension_statistics(x, s, 0)
+    got = M(x, s).compute_dimension_statistics(0)
+    np.testing.assert_allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=1e-10)
+    # the same columns as rows of a 3-D array: axis (0, 1) -> hm_channel_statistics, axis 1 -> hm_axis_statistics (other kernels, same rule)
+    x3, s3 = x.reshape(50, 100, c), s.reshape(50, 100, c)
+    with np.errstate(all="ignore"):
+        ref = orc.dimension_statistics(x3, s3, (0, 1))
+    got = M(x3, s3).compute_dimension_statistics((0, 1))
+    np.testing.assert_allclose(got["std"].cpu().numpy(), ref["std"], rtol=1e-10)

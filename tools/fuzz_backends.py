@@ -432,11 +432,17 @@ def case_linearity(rng):
     sb = None if stds is None else [Hh(v) for v in stds]
     ra = engine.pairs_statistics(va, sa, pairs, to_host=True, thresholds=thr)
     rb = heng.pairs_statistics(vb, sb, pairs, to_host=True, thresholds=thr)
+    if args.one:                                                       # inputs and both answers, for a look on the host (e.g. in extended precision)
+        np.savez("gpurun_out/fuzz_case_linearity.npz", vals=np.stack(vals), stds=np.zeros(0) if stds is None else np.stack(stds), pairs=np.array(pairs),
+                 dev=np.array([[[as_np(h[k_]) for k_ in ("mean", "std")] for h in pr] for pr in ra]),
+                 host=np.array([[[as_np(h[k_]) for k_ in ("mean", "std")] for h in pr] for pr in rb]))
     # Without thresholds the relative difference is heavy-tailed (y near 0: values 1e4 and more beside a spread of 1e-2). The device's
     # one-pass moments take their first shift K from a lane's first element: when that one is such an outlier, the lane's first 64-element
-    # block carries eps (K - mean)^2 / sigma^2 of relative error (seen: up to 1e-7 on the std) where the host's two-pass form has eps n.
+    # block carries eps (K - mean)^2 / sigma^2 of relative error (seen: up to 2.8e-6 on the std - a first element of 1.4e6 with weight 4e-12
+    # beside values of 0.05 with weight 54) where the host's two-pass form has eps n. (The HBM-bound statistics kernels take the heavier of a
+    # lane's first two elements as the shift and do not have this limit: case_stats compares them at 1e-9.)
     # The reference's own use thresholds first (modules/exposure_series.py:431): bounded data, 1e-9.
-    std_tol = 1e-9 if thr is not None else float(__import__('os').environ.get('FUZZ_LIN_TOL', '1e-6'))
+    std_tol = 1e-9 if thr is not None else float(__import__('os').environ.get('FUZZ_LIN_TOL', '1e-5'))
     for q, ((aa, ar), (ba, br)) in enumerate(zip(ra, rb)):
         for nm, x_, y_ in (("abs", aa, ba), ("rel", ar, br)):
             for key in y_:
